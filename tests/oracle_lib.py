@@ -1,0 +1,206 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+this module; the product path never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+MAX_TABLE = 16
+MAX_COEF = 8
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("dt", C.c_double), ("ipopt_timeout", C.c_double), ("latency", C.c_long),
+        ("lookahead", C.c_double), ("max_fit_order", C.c_int), ("max_fit_error", C.c_double),
+        ("max_steering", C.c_double), ("max_acceleration", C.c_double), ("max_deceleration", C.c_double),
+        ("max_speed", C.c_double), ("yaw_low", C.c_double), ("yaw_high", C.c_double),
+        ("steer_adj_thresh", C.c_double), ("steer_adj_ratio", C.c_double), ("Lf", C.c_double),
+        ("cte_panic", C.c_double), ("epsi_panic", C.c_double), ("n_weights", C.c_int),
+        ("weights", C.c_double * MAX_TABLE),
+        ("n_steers", C.c_int), ("n_steer_speeds", C.c_int), ("n_yaw_changes", C.c_int),
+        ("n_yaw_change_speeds", C.c_int),
+        ("steers", C.c_double * MAX_TABLE), ("steer_speeds", C.c_double * MAX_TABLE),
+        ("yaw_changes", C.c_double * MAX_TABLE), ("yaw_change_speeds", C.c_double * MAX_TABLE),
+    ]
+
+
+class OrcSolveOptions(C.Structure):
+    _fields_ = [("branch_mode", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
+                ("lam_init_ls", C.c_int), ("obj_scaling", C.c_int), ("verbose", C.c_int)]
+
+
+class OrcSolveInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("kkt_error", C.c_double), ("mu", C.c_double),
+                ("obj", C.c_double), ("constr_viol", C.c_double), ("dual_inf", C.c_double),
+                ("compl_inf", C.c_double), ("n_regularised", C.c_int), ("n_backtracks", C.c_int)]
+
+
+class OrcRunPre(C.Structure):
+    _fields_ = [("nc", C.c_int), ("coef", C.c_double * MAX_COEF), ("state", C.c_double * 6),
+                ("max_yaw_change", C.c_double), ("max_speed", C.c_double), ("target_speed", C.c_double),
+                ("yaw_low", C.c_double), ("yaw_high", C.c_double)]
+
+
+_lib = None
+DP = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "mpc_oracle.c")
+        if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+            build()
+        L = C.CDLL(path)
+        L.orc_polyeval.restype = C.c_double
+        L.orc_polyeval.argtypes = [DP, C.c_int, C.c_double]
+        L.orc_polyder.restype = C.c_double
+        L.orc_polyder.argtypes = [DP, C.c_int, C.c_double]
+        L.orc_mph2mps.restype = C.c_double
+        L.orc_mph2mps.argtypes = [C.c_double]
+        L.orc_normalize_angle.restype = C.c_double
+        L.orc_normalize_angle.argtypes = [C.c_double]
+        L.orc_speed_target.restype = C.c_double
+        L.orc_speed_target.argtypes = [C.POINTER(OrcConfig), C.c_double, C.c_double]
+        L.orc_yaw_change_speed_limit.restype = C.c_double
+        L.orc_yaw_change_speed_limit.argtypes = [C.POINTER(OrcConfig), C.c_double, C.c_double]
+        L.orc_compute_throttle.restype = C.c_double
+        L.orc_compute_throttle.argtypes = [C.POINTER(OrcConfig)] + [C.c_double] * 4
+        L.orc_orientation_change.restype = C.c_double
+        L.orc_orientation_change.argtypes = [DP, C.c_int, C.c_double, C.c_double]
+        L.orc_kkt_certificate.restype = C.c_double
+        L.orc_config_load.argtypes = [C.c_char_p, C.POINTER(OrcConfig)]
+        L.orc_polyfit.argtypes = [DP, DP, C.c_int, C.c_int, DP]
+        L.orc_road_fit.argtypes = [DP, DP, C.c_int, C.c_int, C.c_double, DP, DP]
+        L.orc_vehicle_move.argtypes = [C.POINTER(OrcConfig), DP, C.c_double]
+        L.orc_global_to_vehicle.argtypes = [C.c_double] * 3 + [DP, DP, C.c_int]
+        L.orc_fg_eval.argtypes = [C.POINTER(OrcConfig), DP, C.c_int, C.c_int, DP, DP, DP]
+        L.orc_fg_grad.argtypes = [C.POINTER(OrcConfig), DP, C.c_int, C.c_int, DP, DP, DP, DP]
+        L.orc_lag_hess.argtypes = [C.POINTER(OrcConfig), DP, C.c_int, C.c_int, DP, DP, C.c_double, DP, DP]
+        L.orc_mpc_solve.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSolveOptions), DP, DP, C.c_int,
+                                    DP, DP, DP, DP, C.POINTER(OrcSolveInfo)]
+        L.orc_mpc_run_pre.argtypes = [C.POINTER(OrcConfig), DP, DP, DP, C.c_int, C.POINTER(OrcRunPre)]
+        L.orc_mpc_run_post.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcRunPre), C.c_double, DP, DP]
+        L.orc_mpc_run.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSolveOptions), DP, DP, DP, C.c_int, DP,
+                                  DP, DP, C.POINTER(OrcRunPre), C.POINTER(OrcSolveInfo)]
+        L.orc_kkt_certificate.argtypes = [C.POINTER(OrcConfig), DP, DP, C.c_int, DP, C.c_double, DP, DP, DP]
+        _lib = L
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(DP) if a is not None else None
+
+
+def arr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def load_config(name="config-stable.json", **overrides):
+    cfg = OrcConfig()
+    path = name if os.path.isabs(name) else os.path.join(GOLDEN, name)
+    rc = lib().orc_config_load(path.encode(), C.byref(cfg))
+    assert rc == 0, "config load failed: %s" % path
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def default_options(**kw):
+    o = OrcSolveOptions()
+    lib().orc_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def nvars(N):
+    return 8 * N - 2
+
+
+def fg_eval(cfg, coef, vars_, xi=None, branch_mode=0):
+    coef = arr(coef); vars_ = arr(vars_)
+    fg = np.zeros(1 + 6 * cfg.N)
+    xi_a = arr(xi) if xi is not None else None
+    lib().orc_fg_eval(C.byref(cfg), dptr(coef), len(coef), branch_mode, dptr(xi_a), dptr(vars_), dptr(fg))
+    return fg
+
+
+def fg_grad(cfg, coef, vars_, xi=None, branch_mode=0):
+    coef = arr(coef); vars_ = arr(vars_)
+    n = nvars(cfg.N); m = 6 * cfg.N
+    g = np.zeros(n); J = np.zeros((m, n))
+    xi_a = arr(xi) if xi is not None else None
+    lib().orc_fg_grad(C.byref(cfg), dptr(coef), len(coef), branch_mode, dptr(xi_a), dptr(vars_), dptr(g), dptr(J))
+    return g, J
+
+
+def lag_hess(cfg, coef, vars_, obj_factor, lam, xi=None, branch_mode=0):
+    coef = arr(coef); vars_ = arr(vars_); lam = arr(lam)
+    n = nvars(cfg.N)
+    H = np.zeros((n, n))
+    xi_a = arr(xi) if xi is not None else None
+    lib().orc_lag_hess(C.byref(cfg), dptr(coef), len(coef), branch_mode, dptr(xi_a), dptr(vars_),
+                       obj_factor, dptr(lam), dptr(H))
+    return H
+
+
+def mpc_solve(cfg, state, coef, opt=None, want_sol=False):
+    """-> (status, out9, traj_x, traj_y, info[, sol])"""
+    state = arr(state); coef = arr(coef)
+    out9 = np.zeros(9); tx = np.zeros(cfg.N); ty = np.zeros(cfg.N)
+    sol = np.zeros(nvars(cfg.N))
+    info = OrcSolveInfo()
+    opt = opt if opt is not None else default_options()
+    st = lib().orc_mpc_solve(C.byref(cfg), C.byref(opt), dptr(state), dptr(coef), len(coef), dptr(out9),
+                             dptr(tx), dptr(ty), dptr(sol), C.byref(info))
+    if want_sol:
+        return st, out9, tx, ty, info, sol
+    return st, out9, tx, ty, info
+
+
+def run_pre(cfg, pose, ptsx, ptsy):
+    """-> (OrcRunPre, ptsx_vehicle, ptsy_vehicle)"""
+    pose = arr(pose); px = arr(ptsx).copy(); py = arr(ptsy).copy()
+    pre = OrcRunPre()
+    lib().orc_mpc_run_pre(C.byref(cfg), dptr(pose), dptr(px), dptr(py), len(px), C.byref(pre))
+    return pre, px, py
+
+
+def run_post(cfg, pre, v0, result9):
+    r = arr(result9); out8 = np.zeros(8)
+    lib().orc_mpc_run_post(C.byref(cfg), C.byref(pre), v0, dptr(r), dptr(out8))
+    return out8
+
+
+def mpc_run(cfg, pose, ptsx, ptsy, opt=None):
+    """-> (status, out8, traj_x, traj_y, pre, info); cfg.yaw_low/high are mutated like the reference."""
+    pose = arr(pose); px = arr(ptsx).copy(); py = arr(ptsy).copy()
+    out8 = np.zeros(8); tx = np.zeros(cfg.N); ty = np.zeros(cfg.N)
+    pre = OrcRunPre(); info = OrcSolveInfo()
+    opt = opt if opt is not None else default_options()
+    st = lib().orc_mpc_run(C.byref(cfg), C.byref(opt), dptr(pose), dptr(px), dptr(py), len(px), dptr(out8),
+                           dptr(tx), dptr(ty), C.byref(pre), C.byref(info))
+    return st, out8, tx, ty, pre, info
+
+
+def kkt_certificate(cfg, state, coef, vars_, active_tol=1e-6):
+    state = arr(state); coef = arr(coef); vars_ = arr(vars_)
+    s = C.c_double(); p = C.c_double(); b = C.c_double()
+    tot = lib().orc_kkt_certificate(C.byref(cfg), dptr(state), dptr(coef), len(coef), dptr(vars_),
+                                    active_tol, C.byref(s), C.byref(p), C.byref(b))
+    return tot, s.value, p.value, b.value
