@@ -1,0 +1,19 @@
+"""carnd_mpc_project_amd -- MI355X-native batched MPC solver (host-side Python glue).
+
+The product is the C-ABI library ``lib/libmpc_amd.so`` (HIP kernels for gfx950,
+``include/mpc_amd.h``).  This package only binds it with ctypes, moves batches
+between torch/numpy and the ABI's struct-of-arrays layout, and generates the
+synthetic batches BASELINE.json names.  There is no CPU compute path here: if
+the library is missing or no gfx950 device is present, solving raises.
+
+The directory is called ``carnd-mpc-project_amd`` (not importable as written);
+``__graft_entry__.load_package()`` imports it under the name
+``carnd_mpc_project_amd``.
+"""
+from ._abi import (MpcParams, MpcBatchStats, MpcError, library, library_path, build_library,
+                   params_default, params_from_json, STATUS_NAMES)
+from .solver import BatchedMPC
+from . import scenarios
+
+__all__ = ["MpcParams", "MpcBatchStats", "MpcError", "library", "library_path", "build_library",
+           "params_default", "params_from_json", "BatchedMPC", "scenarios", "STATUS_NAMES"]

@@ -1,0 +1,734 @@
+/*
+ * mpc_core.h -- per-instance solver of the batched MPC path (device code).
+ *
+ * Replaces, for one problem instance, what the reference does inside
+ *   MPC::solve()          src/control/MPC.cpp:183-325
+ *   FG_eval::operator()   src/control/MPC.cpp:50-154
+ *   CppAD::ipopt::solve   src/control/MPC.cpp:290-292  (IPOPT + MUMPS + CppAD)
+ * It is NOT a translation of any of them.  The NLP is the reference's (same
+ * variables, same residuals, same bounds, same start point, branch outcomes
+ * frozen at the start point as CppAD's single tape recording does), but it is
+ * solved by a structure-exploiting direct-multiple-shooting primal-dual
+ * interior-point method:
+ *   - stage structure: s_{k+1} = F(s_k, u_k), k = 0..N-2, s_0 fixed, so the
+ *     KKT matrix is block-banded and every Newton system is solved by ONE
+ *     Riccati sweep (backward gains, forward roll-out, backward costates)
+ *     instead of a general sparse LDL^T; O(N) work, no fill, no pivoting;
+ *   - analytic stage Jacobians/Hessians (no AD tape);
+ *   - the steering-rate term w4 (delta_{k+1}-delta_k)^2 (MPC.cpp:110) is
+ *     carried by augmenting the stage state with d_k = delta_{k-1};
+ *   - cte is a pure output state (its column of dF/ds is zero), so it is kept
+ *     out of the 6x6 Riccati matrix as a scalar;
+ *   - inertia correction = "every 2x2 R~_k positive definite", the Riccati
+ *     equivalent of IPOPT's inertia test on the full KKT matrix.
+ * Interior-point logic (monotone barrier, fraction-to-the-boundary, filter
+ * line search, kappa_sigma dual reset, error scaling, gradient-based
+ * objective scaling) follows Waechter & Biegler (2006) with IPOPT's default
+ * constants so that the converged point is the one IPOPT's tolerance defines.
+ *
+ * Mapping to the hardware: ONE INSTANCE PER LANE, 64 instances per wavefront.
+ * Every instruction a wave issues is useful fp64 work for 64 independent
+ * problems; there is no cross-lane traffic and no divergence except in
+ * iteration counts.  All per-stage data live in a struct-of-arrays workspace
+ * indexed [stage][field][instance] so that each load/store of a wave is one
+ * fully coalesced 512-byte access.  (See DESIGN.md for why this beats one
+ * instance per wavefront for 7x7 blocks.)
+ *
+ * The same header compiles with g++ for tests/host_twin.cpp, a test-only CPU
+ * build used to debug the algorithm in the GPU-less build container; the
+ * shipped library contains the HIP build only.
+ */
+#ifndef MPC_CORE_H
+#define MPC_CORE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include "mpc_amd.h"
+
+#if defined(__HIPCC__)
+#define MPC_HD __host__ __device__ __forceinline__
+#define MPC_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define MPC_HD inline
+#define MPC_HD_NOINLINE
+#endif
+
+namespace mpc {
+
+/* ---- workspace layout (doubles per stage) -------------------------------- */
+/* Stage k (0..N-2) owns: s_{k+1}, u_k, lam_{k+1}, the bound duals of
+ * (psi_{k+1}, v_{k+1}, delta_k, a_k), the model cache of (s_k,u_k) incl. the
+ * residual c_{k+1}, the Newton direction and the Riccati gains of u_k. */
+enum : int {
+  F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
+  IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
+  MC0 = 2 * IT_SZ, MC_SZ = 14, MC1 = MC0 + MC_SZ,                  /* double-buffered model cache */
+  F_D = MC1 + MC_SZ,                                               /* ds[6] du[2] dlam[6] */
+  D_SZ = 14,
+  F_G = F_D + D_SZ,                                                /* K[2][6] kff[2] */
+  G_SZ = 14,
+  STAGE_SZ = F_G + G_SZ
+};
+enum : int { MC_SP = 0, MC_CP, MC_SE, MC_CE, MC_FP, MC_G1, MC_H3, MC_FPP, MC_C = 8 };
+
+MPC_HD int64_t workspace_doubles_per_instance(int N) { return (int64_t)(N - 1) * STAGE_SZ; }
+
+/* Workspace accessor for struct-of-arrays storage: element e of instance i is
+ * at base[e * stride + i]. */
+struct SoaWorkspace {
+  double *base;
+  int64_t stride;
+  MPC_HD double &operator()(int k, int f) const { return base[(int64_t)(k * STAGE_SZ + f) * stride]; }
+};
+
+/* IPOPT default constants (Waechter & Biegler 2006; IPOPT 3.12 option defaults) */
+struct IpmConst {
+  static constexpr double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, s_max = 100.0;
+  static constexpr double gamma_theta = 1e-5, gamma_phi = 1e-8, delta_sw = 1.0, s_theta = 1.1, s_phi = 2.3;
+  static constexpr double eta_phi = 1e-8, gamma_alpha = 0.05, kappa_sigma = 1e10, kappa1 = 1e-2, kappa2 = 1e-2;
+  static constexpr double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, kw_minus = 1.0 / 3.0, kw_plus = 8.0;
+  static constexpr double kw_plus_bar = 100.0, mu_init = 0.1, eps = 2.220446049250313e-16;
+};
+
+/* Vehicle::computeSpeedTarget, src/model/Vehicle.cpp:34-64 */
+MPC_HD double speed_target(const MpcParams &P, double angle, double maxv) {
+  double y = fabs(angle);
+  int last = P.n_steer_speeds - 1;
+  for (int i = 0; i < P.n_steers; i++) {
+    if (y <= P.steers[i]) {
+      if (P.n_steer_speeds > i) return fmin(P.steer_speeds[i], maxv);
+      return fmin(P.steer_speeds[last], maxv);
+    }
+  }
+  return fmin(P.steer_speeds[last], maxv);
+}
+
+/* what a trial-point evaluation returns */
+struct Eval {
+  double theta;  /* ||c||_1            */
+  double cinf;   /* ||c||_inf          */
+  double f;      /* unscaled objective without the stage-0 constant */
+  double L;      /* sum of log(slack)  */
+  double dinf;   /* ||grad_x Lagrangian||_inf (scaled objective) */
+  double cmin, cmax; /* range of slack*dual products */
+  double lsum, zsum; /* ||lam||_1, ||z||_1 */
+  bool ok;
+};
+
+template <class WS>
+struct Solver {
+  const MpcParams &P;
+  WS ws;
+  /* instance data */
+  double st[6], coef[MPC_NCOEF], yl, yu;
+  double wc, we, wv, wd, wdd, vref, cost0;
+  /* bounds */
+  double vl, vu, dl, du, al, au;
+  int M;       /* number of stages = N-1 */
+  double dt, dtLf;
+  /* interior-point state */
+  int cur;     /* slot of the current iterate / model cache */
+  double mu, tau, df;
+  Eval E;
+  /* direction summary */
+  double amax, az, dphi, dxinf, xinf;
+  /* filter */
+  enum { FMAX = 8 };
+  double fth[FMAX], fph[FMAX];
+  int nf;
+  int iters, n_reg;
+
+  MPC_HD Solver(const MpcParams &p, WS w) : P(p), ws(w) {}
+
+  MPC_HD int it(int slot) const { return slot ? IT1 : IT0; }
+  MPC_HD int mc(int slot) const { return slot ? MC1 : MC0; }
+
+  /* ---- road polynomial: RoadGeometry::centerY / orientation, utils.h:28-47 */
+  MPC_HD void poly(double x, double &f, double &fp, double &fpp, double &fppp) const {
+    const double c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4];
+    f = (((c4 * x + c3) * x + c2) * x + c1) * x + c0;
+    fp = ((4.0 * c4 * x + 3.0 * c3) * x + 2.0 * c2) * x + c1;
+    fpp = (12.0 * c4 * x + 6.0 * c3) * x + 2.0 * c2;
+    fppp = 24.0 * c4 * x + 6.0 * c3;
+  }
+
+  /* model of stage k at (s,u): trig cache + F(s,u), MPC.cpp:142-152 */
+  MPC_HD void model(const double *s, double delta, double a, double *m8, double *F) const {
+    double sp, cp, se, ce;
+    ::sincos(s[2], &sp, &cp);
+    ::sincos(s[5], &se, &ce);
+    double f, fp, fpp, fppp;
+    poly(s[0], f, fp, fpp, fppp);
+    const double q1 = 1.0 + fp * fp;
+    m8[MC_SP] = sp; m8[MC_CP] = cp; m8[MC_SE] = se; m8[MC_CE] = ce; m8[MC_FP] = fp;
+    m8[MC_G1] = fpp / q1;
+    m8[MC_H3] = (fppp * q1 - 2.0 * fp * fpp * fpp) / (q1 * q1);
+    m8[MC_FPP] = fpp;
+    const double vdt = s[3] * dt;
+    const double psin = s[2] + delta * vdt / P.Lf;
+    F[0] = s[0] + cp * vdt;
+    F[1] = s[1] + sp * vdt;
+    F[2] = psin;
+    F[3] = s[3] + a * dt;
+    F[4] = (f - s[1]) + se * vdt;
+    F[5] = psin - atan(fp);
+  }
+
+  /* cost + barrier terms of one state s_k (k>=1): Hessian diagonal and gradient */
+  MPC_HD void state_terms(double psi, double v, double c, double e, double zlp, double zup, double zlv,
+                          double zuv, double &Hpp, double &Hvv, double &Hee, double &Hcc, double &gp,
+                          double &gv, double &ge, double &gc) const {
+    const double slp = psi - yl, sup = yu - psi, slv = v - vl, suv = vu - v;
+    Hpp = zlp / slp + zup / sup;
+    Hvv = df * 2.0 * wv + zlv / slv + zuv / suv;
+    Hee = df * 2.0 * we;
+    Hcc = df * 2.0 * wc;
+    gp = -mu / slp + mu / sup;
+    gv = df * 2.0 * wv * (v - vref) - mu / slv + mu / suv;
+    ge = df * 2.0 * we * e;
+    gc = df * 2.0 * wc * c;
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* Riccati backward sweep: gains K_k, kff_k for every stage.           */
+  /* Returns false when some R~_k is not positive definite (wrong        */
+  /* inertia): the caller raises the regularisation dw and repeats.      */
+  /* ------------------------------------------------------------------ */
+  MPC_HD bool backward(double dw) {
+    const int I = it(cur), C = mc(cur);
+    double Pm[6][6], p[6], Pcc, pc; /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1 */
+    for (int i = 0; i < 6; i++) { p[i] = 0; for (int j = 0; j < 6; j++) Pm[i][j] = 0; }
+    {
+      const int ks = M - 1;
+      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
+                  ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
+                  Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      Pm[0][0] = dw; Pm[1][1] = dw; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
+      Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
+    }
+    for (int k = M - 1; k >= 0; --k) {
+      /* ---- linearisation of stage k ---- */
+      double v, psi_k = 0, c_k = 0, e_k = 0;
+      if (k == 0) { v = st[3]; }
+      else { psi_k = ws(k - 1, I + F_S + 2); v = ws(k - 1, I + F_S + 3); c_k = ws(k - 1, I + F_S + 4); e_k = ws(k - 1, I + F_S + 5); }
+      const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
+      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
+      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
+      const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
+      const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
+      const double vdt = v * dt;
+      const double Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
+      const double Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
+      /* r = -c_{k+1}; t = p + P r (d component of r is zero) */
+      const double r0 = -ws(k, C + MC_C + 0), r1 = -ws(k, C + MC_C + 1), r2 = -ws(k, C + MC_C + 2);
+      const double r3 = -ws(k, C + MC_C + 3), rc = -ws(k, C + MC_C + 4), r4 = -ws(k, C + MC_C + 5);
+      double t[6];
+      for (int i = 0; i < 6; i++)
+        t[i] = p[i] + Pm[i][0] * r0 + Pm[i][1] * r1 + Pm[i][2] * r2 + Pm[i][3] * r3 + Pm[i][4] * r4;
+      const double tc = pc + Pcc * rc;
+      /* G^T applied to a (6-vector, c-scalar): outputs for inputs x,y,psi,v,e,delta,a */
+#define MPC_GT(w, wcs, o)                                                         \
+  do {                                                                            \
+    const double w24_ = (w)[2] + (w)[4];                                          \
+    (o)[0] = (w)[0] + Aex * (w)[4] + Acx * (wcs);                                 \
+    (o)[1] = (w)[1] - (wcs);                                                      \
+    (o)[2] = Axp * (w)[0] + Ayp * (w)[1] + w24_;                                  \
+    (o)[3] = Axv * (w)[0] + Ayv * (w)[1] + Apv * w24_ + (w)[3] + Acv * (wcs);     \
+    (o)[4] = Ace * (wcs);                                                         \
+    (o)[5] = Bp * w24_ + (w)[5];                                                  \
+    (o)[6] = dt * (w)[3];                                                         \
+  } while (0)
+      double qt[7];
+      MPC_GT(t, tc, qt);
+      /* gradient of the stage's own control terms */
+      const double sld = delta - dl, sud = du - delta, sla = acc - al, sua = au - acc;
+      const double zld = ws(k, I + F_ZL + 2), zud = ws(k, I + F_ZU + 2), zla = ws(k, I + F_ZL + 3), zua = ws(k, I + F_ZU + 3);
+      double ddl = 0, Hdd = 0;
+      if (k >= 1) { ddl = delta - ws(k - 1, I + F_U + 0); Hdd = df * 2.0 * wdd; }
+      const double gdel = df * 2.0 * wd * delta + Hdd * ddl - mu / sld + mu / sud;
+      const double gacc = -mu / sla + mu / sua;
+      const double rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
+      if (k == 0) {
+        /* only the feed-forward of u_0 is needed (ds_0 = 0) */
+        double w5[6], o5[7], w6[6], o6[7];
+        for (int i = 0; i < 6; i++) { w5[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5]; w6[i] = dt * Pm[i][3]; }
+        MPC_GT(w5, 0.0, o5);
+        MPC_GT(w6, 0.0, o6);
+        const double Rdd = o5[5] + df * 2.0 * wd + zld / sld + zud / sud + dw;
+        const double Rda = o6[5];
+        const double Raa = o6[6] + zla / sla + zua / sua + dw;
+        const double det = Rdd * Raa - Rda * Rda;
+        if (!(Rdd > 0.0) || !(det > 0.0)) return false;
+        ws(0, F_G + 12) = -(Raa * rt_d - Rda * rt_a) / det;
+        ws(0, F_G + 13) = -(-Rda * rt_d + Rdd * rt_a) / det;
+        break;
+      }
+      /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
+      double Mx[7][7];
+      {
+        double w[6], o[7];
+        for (int i = 0; i < 6; i++) w[i] = Pm[i][0] + Aex * Pm[i][4];
+        MPC_GT(w, Pcc * Acx, o);
+        for (int i = 0; i < 7; i++) Mx[i][0] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = Pm[i][1];
+        MPC_GT(w, -Pcc, o);
+        for (int i = 0; i < 7; i++) Mx[i][1] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = Axp * Pm[i][0] + Ayp * Pm[i][1] + Pm[i][2] + Pm[i][4];
+        MPC_GT(w, 0.0, o);
+        for (int i = 0; i < 7; i++) Mx[i][2] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = Axv * Pm[i][0] + Ayv * Pm[i][1] + Apv * (Pm[i][2] + Pm[i][4]) + Pm[i][3];
+        MPC_GT(w, Pcc * Acv, o);
+        for (int i = 0; i < 7; i++) Mx[i][3] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = 0.0;
+        MPC_GT(w, Pcc * Ace, o);
+        for (int i = 0; i < 7; i++) Mx[i][4] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5];
+        MPC_GT(w, 0.0, o);
+        for (int i = 0; i < 7; i++) Mx[i][5] = o[i];
+        for (int i = 0; i < 6; i++) w[i] = dt * Pm[i][3];
+        MPC_GT(w, 0.0, o);
+        for (int i = 0; i < 7; i++) Mx[i][6] = o[i];
+      }
+      /* ---- add the Lagrangian Hessian of stage k: -lam_{k+1}^T d2F ---- */
+      Mx[0][0] += -lc * fpp + le * h3;
+      Mx[2][2] += (lx * cp + ly * sp) * vdt;
+      { const double h = (lx * sp - ly * cp) * dt; Mx[2][3] += h; Mx[3][2] += h; }
+      Mx[4][4] += lc * vdt * se;
+      { const double h = -lc * dt * ce; Mx[3][4] += h; Mx[4][3] += h; }
+      { const double h = -(lp + le) * dtLf; Mx[3][5] += h; Mx[5][3] += h; }
+      /* control terms */
+      const double Rdd = Mx[5][5] + df * 2.0 * wd + Hdd + zld / sld + zud / sud + dw;
+      const double Rda = 0.5 * (Mx[5][6] + Mx[6][5]);
+      const double Raa = Mx[6][6] + zla / sla + zua / sua + dw;
+      const double det = Rdd * Raa - Rda * Rda;
+      if (!(Rdd > 0.0) || !(det > 0.0)) return false;
+      const double i11 = Raa / det, i12 = -Rda / det, i22 = Rdd / det;
+      /* S~ (2 x 6 over x,y,psi,v,e,d) */
+      double Sd[6], Sa[6], Kd[6], Ka[6];
+      for (int j = 0; j < 5; j++) { Sd[j] = Mx[5][j]; Sa[j] = Mx[6][j]; }
+      Sd[5] = -Hdd; Sa[5] = 0.0;
+      for (int j = 0; j < 6; j++) {
+        Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
+        Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
+        ws(k, F_G + j) = Kd[j];
+        ws(k, F_G + 6 + j) = Ka[j];
+      }
+      const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
+      ws(k, F_G + 12) = kfd;
+      ws(k, F_G + 13) = kfa;
+      /* ---- value function of stage k ---- */
+      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      state_terms(psi_k, v, c_k, e_k, ws(k - 1, I + F_ZL + 0), ws(k - 1, I + F_ZU + 0), ws(k - 1, I + F_ZL + 1),
+                  ws(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      for (int i = 0; i < 6; i++) {
+        for (int j = 0; j <= i; j++) {
+          double q = (i < 5) ? 0.5 * (Mx[i][j] + Mx[j][i]) : ((j == 5) ? Hdd : 0.0);
+          q += Sd[i] * Kd[j] + Sa[i] * Ka[j];
+          Pm[i][j] = q; Pm[j][i] = q;
+        }
+        p[i] = ((i < 5) ? qt[i] : -Hdd * ddl) + Sd[i] * kfd + Sa[i] * kfa;
+      }
+      Pm[0][0] += dw; Pm[1][1] += dw; Pm[2][2] += Hpp + dw; Pm[3][3] += Hvv + dw; Pm[4][4] += Hee + dw;
+      p[2] += gp; p[3] += gv; p[4] += ge;
+      Pcc = Hcc + dw; pc = gc;
+    }
+#undef MPC_GT
+    return true;
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* forward sweep: Newton direction ds, du; step limits; dphi           */
+  /* ------------------------------------------------------------------ */
+  MPC_HD void forward() {
+    const int I = it(cur), C = mc(cur);
+    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0; /* ds_k: x,y,psi,v,c,e */
+    double ddprev = 0, delprev = 0;                         /* d(delta_{k-1}), delta_{k-1} */
+    amax = 1.0; az = 1.0; dphi = 0.0; dxinf = 0.0; xinf = 0.0;
+    for (int k = 0; k < M; ++k) {
+      const double v = (k == 0) ? st[3] : ws(k - 1, I + F_S + 3);
+      const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
+      double dd = ws(k, F_G + 12), da = ws(k, F_G + 13);
+      if (k > 0) {
+        dd += ws(k, F_G + 0) * d0 + ws(k, F_G + 1) * d1 + ws(k, F_G + 2) * d2 + ws(k, F_G + 3) * d3 +
+              ws(k, F_G + 4) * d5 + ws(k, F_G + 5) * ddprev;
+        da += ws(k, F_G + 6) * d0 + ws(k, F_G + 7) * d1 + ws(k, F_G + 8) * d2 + ws(k, F_G + 9) * d3 +
+              ws(k, F_G + 10) * d5 + ws(k, F_G + 11) * ddprev;
+      }
+      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
+      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1);
+      const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
+      const double n0 = d0 - vdt * sp * d2 + dt * cp * d3 - ws(k, C + MC_C + 0);
+      const double n1 = d1 + vdt * cp * d2 + dt * sp * d3 - ws(k, C + MC_C + 1);
+      const double n2 = d2 + Apv * d3 + Bp * dd - ws(k, C + MC_C + 2);
+      const double n3 = d3 + dt * da - ws(k, C + MC_C + 3);
+      const double n4 = fp * d0 - d1 + dt * se * d3 + vdt * ce * d5 - ws(k, C + MC_C + 4);
+      const double n5 = -g1 * d0 + d2 + Apv * d3 + Bp * dd - ws(k, C + MC_C + 5);
+      ws(k, F_D + 0) = n0; ws(k, F_D + 1) = n1; ws(k, F_D + 2) = n2; ws(k, F_D + 3) = n3;
+      ws(k, F_D + 4) = n4; ws(k, F_D + 5) = n5; ws(k, F_D + 6) = dd; ws(k, F_D + 7) = da;
+      /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
+      const double xs[4] = {ws(k, I + F_S + 2), ws(k, I + F_S + 3), delta, acc};
+      const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+      const double dx[4] = {n2, n3, dd, da};
+      for (int b = 0; b < 4; b++) {
+        const double sl = xs[b] - lo[b], su = hi[b] - xs[b];
+        const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
+        if (dx[b] < 0.0) amax = fmin(amax, -tau * sl / dx[b]);
+        if (dx[b] > 0.0) amax = fmin(amax, tau * su / dx[b]);
+        const double dzl = mu / sl - zl - zl / sl * dx[b];
+        const double dzu = mu / su - zu + zu / su * dx[b];
+        if (dzl < 0.0) az = fmin(az, -tau * zl / dzl);
+        if (dzu < 0.0) az = fmin(az, -tau * zu / dzu);
+        dphi += (-mu / sl + mu / su) * dx[b];
+      }
+      /* objective part of the directional derivative */
+      const double cn = ws(k, I + F_S + 4), en = ws(k, I + F_S + 5), vn = xs[1];
+      double g = 2.0 * wc * cn * n4 + 2.0 * we * en * n5 + 2.0 * wv * (vn - vref) * n3 + 2.0 * wd * delta * dd;
+      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (dd - ddprev);
+      dphi += df * g;
+      dxinf = fmax(dxinf, fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
+                               fmax(fmax(fabs(n4), fabs(n5)), fmax(fabs(dd), fabs(da)))));
+      xinf = fmax(xinf, fmax(fmax(fabs(ws(k, I + F_S + 0)), fabs(ws(k, I + F_S + 1))), fmax(fabs(vn), fabs(cn))));
+      d0 = n0; d1 = n1; d2 = n2; d3 = n3; d4 = n4; d5 = n5; ddprev = dd; delprev = delta;
+    }
+    (void)d4;
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* backward costate sweep: full-step multipliers lam+ -> dlam           */
+  /* (the state rows of the Newton system, solved for lam+)               */
+  /* ------------------------------------------------------------------ */
+  MPC_HD void costate(double dw) {
+    const int I = it(cur), C = mc(cur);
+    double L0, L1, L2, L3, L4, L5; /* lam+_{k+1}: x,y,psi,v,c,e */
+    {
+      const int ks = M - 1;
+      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
+                  ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
+                  Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      L0 = -(dw * ws(ks, F_D + 0));
+      L1 = -(dw * ws(ks, F_D + 1));
+      L2 = -(gp + (Hpp + dw) * ws(ks, F_D + 2));
+      L3 = -(gv + (Hvv + dw) * ws(ks, F_D + 3));
+      L4 = -(gc + (Hcc + dw) * ws(ks, F_D + 4));
+      L5 = -(ge + (Hee + dw) * ws(ks, F_D + 5));
+      ws(ks, F_D + 8) = L0 - ws(ks, I + F_LAM + 0); ws(ks, F_D + 9) = L1 - ws(ks, I + F_LAM + 1);
+      ws(ks, F_D + 10) = L2 - ws(ks, I + F_LAM + 2); ws(ks, F_D + 11) = L3 - ws(ks, I + F_LAM + 3);
+      ws(ks, F_D + 12) = L4 - ws(ks, I + F_LAM + 4); ws(ks, F_D + 13) = L5 - ws(ks, I + F_LAM + 5);
+    }
+    for (int k = M - 1; k >= 1; --k) {
+      const double psi = ws(k - 1, I + F_S + 2), v = ws(k - 1, I + F_S + 3), c = ws(k - 1, I + F_S + 4), e = ws(k - 1, I + F_S + 5);
+      const double delta = ws(k, I + F_U + 0);
+      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
+      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
+      const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
+      const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
+      const double vdt = v * dt, Apv = delta * dtLf;
+      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      state_terms(psi, v, c, e, ws(k - 1, I + F_ZL + 0), ws(k - 1, I + F_ZU + 0), ws(k - 1, I + F_ZL + 1),
+                  ws(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      const double dxk = ws(k - 1, F_D + 0), dyk = ws(k - 1, F_D + 1), dpk = ws(k - 1, F_D + 2), dvk = ws(k - 1, F_D + 3);
+      const double dck = ws(k - 1, F_D + 4), dek = ws(k - 1, F_D + 5), ddk = ws(k, F_D + 6);
+      /* curvature of stage k */
+      const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
+      const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+      const double L25 = L2 + L5;
+      const double n0 = L0 + fp * L4 - g1 * L5 - (Hxx + dw) * dxk;
+      const double n1 = L1 - L4 - dw * dyk;
+      const double n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * dpk - Hpv * dvk;
+      const double n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * dpk -
+                        (Hvv + dw) * dvk - Hev * dek - Hvd * ddk;
+      const double n4 = -gc - (Hcc + dw) * dck;
+      const double n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * dek - Hev * dvk;
+      L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
+      ws(k - 1, F_D + 8) = L0 - ws(k - 1, I + F_LAM + 0); ws(k - 1, F_D + 9) = L1 - ws(k - 1, I + F_LAM + 1);
+      ws(k - 1, F_D + 10) = L2 - ws(k - 1, I + F_LAM + 2); ws(k - 1, F_D + 11) = L3 - ws(k - 1, I + F_LAM + 3);
+      ws(k - 1, F_D + 12) = L4 - ws(k - 1, I + F_LAM + 4); ws(k - 1, F_D + 13) = L5 - ws(k - 1, I + F_LAM + 5);
+    }
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* trial point: iterate(cur) + alpha * direction -> slot 1-cur, with    */
+  /* residuals, objective, barrier, and the optimality error pieces.      */
+  /* ------------------------------------------------------------------ */
+  MPC_HD Eval trial(double alpha, double alpha_z) {
+    const int I = it(cur), J = it(1 - cur), CJ = mc(1 - cur);
+    Eval R;
+    R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.ok = true;
+    double s[6] = {st[0], st[1], st[2], st[3], st[4], st[5]};
+    double lamk[6] = {0, 0, 0, 0, 0, 0};   /* lam_k of the trial point (k>=1) */
+    double zs[4] = {0, 0, 0, 0};           /* zl_psi, zu_psi, zl_v, zu_v of s_k */
+    double rdel_prev = 0, delprev = 0;
+    for (int k = 0; k < M; ++k) {
+      const double delta = ws(k, I + F_U + 0) + alpha * ws(k, F_D + 6);
+      const double acc = ws(k, I + F_U + 1) + alpha * ws(k, F_D + 7);
+      double sn[6], ln[6];
+      for (int i = 0; i < 6; i++) {
+        sn[i] = ws(k, I + F_S + i) + alpha * ws(k, F_D + i);
+        ln[i] = ws(k, I + F_LAM + i) + alpha * ws(k, F_D + 8 + i);
+        ws(k, J + F_S + i) = sn[i];
+        ws(k, J + F_LAM + i) = ln[i];
+        R.lsum += fabs(ln[i]);
+      }
+      ws(k, J + F_U + 0) = delta; ws(k, J + F_U + 1) = acc;
+      double m8[8], F[6];
+      model(s, delta, acc, m8, F);
+      for (int i = 0; i < 8; i++) ws(k, CJ + i) = m8[i];
+      for (int i = 0; i < 6; i++) {
+        const double c = sn[i] - F[i];
+        ws(k, CJ + MC_C + i) = c;
+        R.theta += fabs(c); R.cinf = fmax(R.cinf, fabs(c));
+      }
+      /* duals of psi_{k+1}, v_{k+1}, delta_k, a_k */
+      const double xo[4] = {ws(k, I + F_S + 2), ws(k, I + F_S + 3), ws(k, I + F_U + 0), ws(k, I + F_U + 1)};
+      const double xn[4] = {sn[2], sn[3], delta, acc};
+      const double dxb[4] = {ws(k, F_D + 2), ws(k, F_D + 3), ws(k, F_D + 6), ws(k, F_D + 7)};
+      const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+      double zln[4], zun[4], prod = 1.0;
+      for (int b = 0; b < 4; b++) {
+        const double slo = xo[b] - lo[b], suo = hi[b] - xo[b];
+        const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
+        const double dzl = mu / slo - zl - zl / slo * dxb[b];
+        const double dzu = mu / suo - zu + zu / suo * dxb[b];
+        const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
+        if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
+        double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
+        /* kappa_sigma safeguard, W&B eq. (16) */
+        a = fmax(fmin(a, IpmConst::kappa_sigma * mu / sl), mu / (IpmConst::kappa_sigma * sl));
+        c = fmax(fmin(c, IpmConst::kappa_sigma * mu / su), mu / (IpmConst::kappa_sigma * su));
+        zln[b] = a; zun[b] = c;
+        ws(k, J + F_ZL + b) = a; ws(k, J + F_ZU + b) = c;
+        R.zsum += a + c;
+        const double pl = sl * a, pu = su * c;
+        R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
+        prod *= sl * su;
+      }
+      R.L += log(prod);
+      /* objective */
+      const double dv = sn[3] - vref;
+      R.f += wc * sn[4] * sn[4] + we * sn[5] * sn[5] + wv * dv * dv + wd * delta * delta;
+      const double ddl = (k > 0) ? delta - delprev : 0.0;
+      if (k > 0) R.f += wdd * ddl * ddl;
+      /* dual infeasibility: rows of s_k (k>=1) and u_k; A_k, B_k of the trial point */
+      const double v = s[3], vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
+      const double l25 = ln[2] + ln[5];
+      if (k > 0) {
+        const double r0 = lamk[0] - (ln[0] + m8[MC_FP] * ln[4] - m8[MC_G1] * ln[5]);
+        const double r1 = lamk[1] - (ln[1] - ln[4]);
+        const double r2 = lamk[2] - (-vdt * m8[MC_SP] * ln[0] + vdt * m8[MC_CP] * ln[1] + l25) - zs[0] + zs[1];
+        const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] -
+                          (dt * m8[MC_CP] * ln[0] + dt * m8[MC_SP] * ln[1] + Apv * l25 + ln[3] + dt * m8[MC_SE] * ln[4]) -
+                          zs[2] + zs[3];
+        const double r4 = df * 2.0 * wc * s[4] + lamk[4];
+        const double r5 = df * 2.0 * we * s[5] + lamk[5] - vdt * m8[MC_CE] * ln[4];
+        R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+        /* finish the delta_{k-1} row now that delta_k is known */
+        R.dinf = fmax(R.dinf, fabs(rdel_prev - df * 2.0 * wdd * ddl));
+      }
+      rdel_prev = df * (2.0 * wd * delta + 2.0 * wdd * ddl) - Bp * l25 - zln[2] + zun[2];
+      const double ra = -dt * ln[3] - zln[3] + zun[3];
+      R.dinf = fmax(R.dinf, fabs(ra));
+      /* carry to the next stage */
+      for (int i = 0; i < 6; i++) { s[i] = sn[i]; lamk[i] = ln[i]; }
+      zs[0] = zln[0]; zs[1] = zun[0]; zs[2] = zln[1]; zs[3] = zun[1];
+      delprev = delta;
+    }
+    /* last delta row has no successor; terminal state rows */
+    R.dinf = fmax(R.dinf, fabs(rdel_prev));
+    {
+      const double r2 = lamk[2] - zs[0] + zs[1];
+      const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] - zs[2] + zs[3];
+      const double r4 = df * 2.0 * wc * s[4] + lamk[4];
+      const double r5 = df * 2.0 * we * s[5] + lamk[5];
+      R.dinf = fmax(R.dinf, fmax(fmax(fabs(lamk[0]), fabs(lamk[1])), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+    }
+    if (!(R.theta == R.theta) || !(R.f == R.f) || !(R.L == R.L) || !(R.dinf == R.dinf)) R.ok = false;
+    return R;
+  }
+
+  MPC_HD double kkt_error(const Eval &e, double mu_) const {
+    const double m = 6.0 * M, nb = 8.0 * M;
+    const double sd = fmax(IpmConst::s_max, (e.lsum + e.zsum) / (m + nb)) / IpmConst::s_max;
+    const double sc = fmax(IpmConst::s_max, e.zsum / nb) / IpmConst::s_max;
+    const double compl_ = fmax(fabs(e.cmax - mu_), fabs(e.cmin - mu_));
+    return fmax(fmax(e.dinf / sd, e.cinf), compl_ / sc);
+  }
+
+  MPC_HD bool filter_rejects(double th, double ph) const {
+    for (int i = 0; i < nf; i++)
+      if (th >= fth[i] && ph >= fph[i]) return true;
+    return false;
+  }
+  MPC_HD void filter_add(double th, double ph) {
+    if (nf < FMAX) { fth[nf] = th; fph[nf] = ph; nf++; return; }
+    /* full: overwrite the entry with the largest theta (the least restrictive one) */
+    int w = 0;
+    for (int i = 1; i < FMAX; i++) if (fth[i] > fth[w]) w = i;
+    fth[w] = th; fph[w] = ph;
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* set-up: instance constants, start point (MPC.cpp:204-257)           */
+  /* ------------------------------------------------------------------ */
+  MPC_HD int setup(const double *state6, const double *coef5, double yaw_lo, double yaw_hi, const double *w12) {
+    for (int i = 0; i < 6; i++) st[i] = state6[i];
+    for (int i = 0; i < MPC_NCOEF; i++) coef[i] = coef5[i];
+    yl = yaw_lo; yu = yaw_hi;
+    M = P.N - 1; dt = P.dt; dtLf = P.dt / P.Lf;
+    vl = -P.max_speed; vu = P.max_speed; dl = -P.max_steering; du = P.max_steering;
+    al = P.max_deceleration; au = P.max_acceleration;
+    /* Branch outcomes at the start point xi = (state at index 0, zeros elsewhere):
+     * for i >= 1 every variable is 0, so (MPC.cpp:72-112)
+     *   |cte_i| < ctePanic  -> w[0] unless ctePanic <= 0
+     *   |epsi_i| > epsiPanic -> w[10] only if epsiPanic < 0
+     *   vref_i = computeSpeedTarget(0, maxSpeed); v_i < 0, a_i > 0, a_i < 0,
+     *   a_{i+1} > a_i are all false -> those terms are not on the tape. */
+    wc = (0.0 < P.cte_panic) ? w12[0] : w12[11];
+    we = (0.0 > P.epsi_panic) ? w12[10] : w12[1];
+    wv = w12[2]; wd = w12[3]; wdd = w12[4];
+    vref = speed_target(P, 0.0, P.max_speed);
+    /* i = 0 terms: constants of the objective (their variables are fixed), MPC.cpp:71-92 */
+    const double wc0 = (fabs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
+    const double we0 = (fabs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
+    const double vref0 = speed_target(P, st[2], P.max_speed);
+    cost0 = wc0 * st[4] * st[4] + we0 * st[5] * st[5] + wv * (st[3] - vref0) * (st[3] - vref0);
+    double g0 = fmax(fabs(2.0 * wc0 * st[4]), fabs(2.0 * we0 * st[5]));
+    double gv0 = 2.0 * wv * (st[3] - vref0);
+    if (st[3] < 0.0) { cost0 += w12[9] * st[3] * st[3]; gv0 += 2.0 * w12[9] * st[3]; }
+    g0 = fmax(g0, fabs(gv0));
+    /* gradient-based objective scaling at the start point (IPOPT default) */
+    g0 = fmax(g0, fabs(2.0 * wv * vref));
+    df = (g0 > 100.0) ? fmax(100.0 / g0, 1e-8) : 1.0;
+    /* start point: zeros (MPC.cpp:207-210), pushed into the interior like IPOPT does */
+    double psi0 = 0.0;
+    {
+      const double pl = fmin(IpmConst::kappa1 * fmax(1.0, fabs(yl)), IpmConst::kappa2 * (yu - yl));
+      const double pu = fmin(IpmConst::kappa1 * fmax(1.0, fabs(yu)), IpmConst::kappa2 * (yu - yl));
+      psi0 = fmin(fmax(psi0, yl + pl), yu - pu);
+    }
+    for (int k = 0; k < M; ++k) {
+      for (int i = 0; i < 6; i++) { ws(k, IT0 + F_S + i) = 0.0; ws(k, IT0 + F_LAM + i) = 0.0; }
+      ws(k, IT0 + F_S + 2) = psi0;
+      ws(k, IT0 + F_U + 0) = 0.0; ws(k, IT0 + F_U + 1) = 0.0;
+      for (int b = 0; b < 4; b++) { ws(k, IT0 + F_ZL + b) = 1.0; ws(k, IT0 + F_ZU + b) = 1.0; }
+      for (int i = 0; i < D_SZ; i++) ws(k, F_D + i) = 0.0;
+    }
+    /* the fixed initial state must satisfy its own bounds (MPC.cpp:229-239 vs :269-281) */
+    if (!(st[2] >= yl && st[2] <= yu) || !(fabs(st[3]) <= P.max_speed) || !(yl < yu)) return MPC_STATUS_INFEASIBLE;
+    return MPC_STATUS_SUCCESS;
+  }
+
+  /* ------------------------------------------------------------------ */
+  /* the interior-point iteration                                         */
+  /* ------------------------------------------------------------------ */
+  MPC_HD int solve() {
+    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0;
+    E = trial(0.0, 0.0);
+    cur = 1;
+    if (!E.ok) return MPC_STATUS_NUMERIC;
+    const double theta_max = 1e4 * fmax(1.0, E.theta), theta_min = 1e-4 * fmax(1.0, E.theta);
+    const double mu_floor = P.tol / 10.0;
+    double dw_last = 0.0;
+    for (int iter = 0;; ++iter) {
+      iters = iter;
+      const double E0 = kkt_error(E, 0.0);
+      if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
+      if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
+      if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
+      /* barrier update, W&B eq. (7) */
+      while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
+        mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
+        tau = fmax(IpmConst::tau_min, 1.0 - mu);
+        nf = 0;
+      }
+      /* search direction with inertia correction, W&B section 3.1 */
+      double dw = 0.0;
+      int tries = 0;
+      while (!backward(dw)) {
+        if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
+        else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
+        if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
+      }
+      if (dw > 0.0) { dw_last = dw; n_reg++; }
+      forward();
+      costate(dw);
+      /* filter line search, W&B algorithm A */
+      const double theta_k = E.theta, phi_k = df * E.f - mu * E.L;
+      double amin;
+      if (dphi < 0.0) {
+        double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pow(theta_k, IpmConst::s_theta) / pow(-dphi, IpmConst::s_phi)
+                                           : IpmConst::gamma_theta;
+        amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
+      } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
+      const bool tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
+      double alpha = amax;
+      bool accepted = false, ftype = false;
+      Eval T;
+      for (;;) {
+        T = trial(alpha, az);
+        if (tiny) { accepted = T.ok; ftype = true; break; }
+        if (T.ok) {
+          const double phi_t = df * T.f - mu * T.L;
+          const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
+          if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
+            const bool sw = dphi < 0.0 && alpha * pow(-dphi, IpmConst::s_phi) > IpmConst::delta_sw * pow(theta_k, IpmConst::s_theta);
+            const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
+            if (theta_k <= theta_min && sw) {
+              if (armijo) accepted = true;
+            } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
+                       phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
+              accepted = true;
+            }
+            ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
+          }
+        }
+        if (accepted) break;
+        alpha *= 0.5;
+        if (alpha < amin) break;
+      }
+      if (!accepted) return MPC_STATUS_LINESEARCH;
+      if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
+      cur = 1 - cur;
+      E = T;
+    }
+  }
+
+  /* MPC.cpp:306-324: out9 and the optional N-point trajectory */
+  template <class OutF, class TrajF>
+  MPC_HD void unpack(OutF out, TrajF traj, bool want_traj) const {
+    const int I = it(cur);
+    for (int i = 0; i < 6; i++) out(i) = ws(0, I + F_S + i);
+    out(6) = ws(0, I + F_U + 0);
+    out(7) = ws(0, I + F_U + 1);
+    out(8) = E.f + cost0;
+    if (want_traj) {
+      const int N = P.N;
+      traj(0) = st[0]; traj(N) = st[1];
+      for (int k = 0; k < M; ++k) { traj(k + 1) = ws(k, I + F_S + 0); traj(N + k + 1) = ws(k, I + F_S + 1); }
+    }
+  }
+};
+
+/* One instance, end to end.  Loaders are functors so that the same code serves
+ * the device kernel (struct-of-arrays HBM pointers) and the test-only host twin. */
+template <class WS>
+MPC_HD int solve_instance(const MpcParams &P, WS ws, const double *state6, const double *coef5, double yaw_lo,
+                          double yaw_hi, const double *w12, double *out9, double *traj2N, int *iters_out) {
+  Solver<WS> S(P, ws);
+  int status = S.setup(state6, coef5, yaw_lo, yaw_hi, w12);
+  if (status == MPC_STATUS_SUCCESS) {
+    status = S.solve();
+  } else {
+    S.cur = 0; S.E.f = 0.0; S.iters = 0;
+  }
+  double *o = out9;
+  double *t = traj2N;
+  S.unpack([o](int i) -> double & { return o[i]; }, [t](int i) -> double & { return t[i]; }, traj2N != nullptr);
+  if (iters_out) *iters_out = S.iters;
+  return status;
+}
+
+}  // namespace mpc
+#endif /* MPC_CORE_H */

@@ -1,0 +1,247 @@
+/*
+ * mpc_solver.hip -- gfx950 kernels and the C ABI of include/mpc_amd.h.
+ *
+ * Batched replacement of MPC::solve() (src/control/MPC.cpp:183-325): B
+ * independent instances, one per lane (64 per wavefront), struct-of-arrays in
+ * HBM.  No CPU fallback exists: without a gfx950 device every compute entry
+ * point returns an error.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mpc_core.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define MPC_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+      return MPC_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchronise */
+
+/*
+ * One instance per lane.  Inputs/outputs are [quantity][instance] so that a
+ * wave's access to one quantity is a single contiguous 512-byte transaction.
+ * The workspace is [stage*field][instance] with the same property.
+ */
+__global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
+    const MpcParams P, const int64_t B, const int64_t ld, const double *__restrict__ state,
+    const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
+    const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
+    const int64_t ws_stride) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  double st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+  for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+  if (weights) {
+#pragma unroll
+    for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
+  } else {
+#pragma unroll
+    for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
+  }
+  mpc::SoaWorkspace ws{wsbase + i, ws_stride};
+  mpc::Solver<mpc::SoaWorkspace> S(P, ws);
+  int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
+  if (s == MPC_STATUS_SUCCESS) s = S.solve();
+  else { S.cur = 0; S.E.f = 0.0; S.iters = 0; }
+  double *o = out + i;
+  double *t = traj ? traj + i : nullptr;
+  const int64_t l = ld;
+  S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; },
+           traj != nullptr);
+  status[i] = s;
+  if (iters) iters[i] = S.iters;
+}
+
+}  // namespace
+
+struct MpcHandle {
+  MpcParams params;
+  int device = 0;
+  int64_t max_batch = 0;
+  int64_t ws_stride = 0;
+  double *ws = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  /* device staging for the host-pointer entry point and for statistics */
+  double *d_in = nullptr;     /* state[6] coeffs[5] ylo yhi weights[12] = 25 rows */
+  double *d_out = nullptr;    /* out[9] traj[2N] */
+  int32_t *d_status = nullptr, *d_iters = nullptr;
+  /* last call */
+  int64_t last_B = 0;
+  const int32_t *last_status = nullptr, *last_iters = nullptr;
+  bool timed = false;
+};
+
+static int validate_params(const MpcParams *p) {
+  if (!p) return MPC_ERR_INVALID;
+  if (p->abi_version != MPC_ABI_VERSION) { g_last_error = "MpcParams.abi_version mismatch"; return MPC_ERR_INVALID; }
+  if (p->N < 3 || p->N > MPC_MAX_N) { g_last_error = "N out of range"; return MPC_ERR_INVALID; }
+  if (!(p->dt > 0) || !(p->Lf > 0) || !(p->max_speed > 0) || !(p->max_steering > 0)) { g_last_error = "bad dt/Lf/limits"; return MPC_ERR_INVALID; }
+  if (p->n_steers < 0 || p->n_steers > MPC_MAX_TABLE || p->n_steer_speeds < 1 || p->n_steer_speeds > MPC_MAX_TABLE) { g_last_error = "bad steer tables"; return MPC_ERR_INVALID; }
+  if (p->branch_mode != MPC_BRANCH_FROZEN) { g_last_error = "branch_mode LIVE is not implemented on the device path"; return MPC_ERR_UNSUPPORTED; }
+  if (p->precision != MPC_PRECISION_F64) { g_last_error = "precision F32 is not implemented yet"; return MPC_ERR_UNSUPPORTED; }
+  if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
+  return MPC_OK;
+}
+
+extern "C" int mpc_abi_version(void) { return MPC_ABI_VERSION; }
+extern "C" const char *mpc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, MpcHandle **out) {
+  if (!out || max_batch < 1) return MPC_ERR_INVALID;
+  int rc = validate_params(p);
+  if (rc != MPC_OK) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_last_error = "no HIP device"; return MPC_ERR_NO_DEVICE; }
+  if (device < 0) MPC_HIP_CHECK(hipGetDevice(&device));
+  if (device >= ndev) { g_last_error = "device index out of range"; return MPC_ERR_NO_DEVICE; }
+  MPC_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MPC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return MPC_ERR_NO_DEVICE;
+  }
+  MpcHandle *h = new MpcHandle();
+  h->params = *p; h->device = device; h->max_batch = max_batch;
+  h->ws_stride = (max_batch + 63) / 64 * 64;
+  const size_t ws_bytes = (size_t)mpc::workspace_doubles_per_instance(p->N) * (size_t)h->ws_stride * sizeof(double);
+  auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+  if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+  if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
+  if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->ws_stride)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->ws_stride)) != hipSuccess) return fail(e, "hipMalloc");
+  *out = h;
+  return MPC_OK;
+}
+
+extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
+  if (!h) return MPC_ERR_INVALID;
+  int rc = validate_params(p);
+  if (rc != MPC_OK) return rc;
+  if (p->N != h->params.N) { g_last_error = "N cannot change on a live handle (workspace is sized by N)"; return MPC_ERR_INVALID; }
+  h->params = *p;
+  return MPC_OK;
+}
+
+extern "C" void mpc_destroy(MpcHandle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->d_in) (void)hipFree(h->d_in);
+  if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_status) (void)hipFree(h->d_status);
+  if (h->d_iters) (void)hipFree(h->d_iters);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                                      const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                      const double *weights, double *out, double *traj, int32_t *status,
+                                      int32_t *iters, void *stream_) {
+  if (!h || !state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
+  if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
+  h->last_B = B; h->last_status = status; h->last_iters = iters ? iters : h->d_iters; h->timed = false;
+  if (B == 0) return MPC_OK;
+  hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+  const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
+  MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(mpc_solve_kernel, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs, yaw_lo,
+                     yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+  MPC_HIP_CHECK(hipGetLastError());
+  MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  return MPC_OK;
+}
+
+extern "C" int mpc_synchronize(MpcHandle *h) {
+  if (!h) return MPC_ERR_INVALID;
+  MPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return MPC_OK;
+}
+
+extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                                    const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                    const double *weights, double *out, double *traj, int32_t *status,
+                                    int32_t *iters) {
+  if (!h || !state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
+  if (B == 0) return MPC_OK;
+  MPC_HIP_CHECK(hipSetDevice(h->device));
+  const int N = h->params.N;
+  const int64_t S = h->ws_stride;
+  if (!h->d_in) MPC_HIP_CHECK(hipMalloc((void **)&h->d_in, sizeof(double) * 25 * S));
+  if (!h->d_out) MPC_HIP_CHECK(hipMalloc((void **)&h->d_out, sizeof(double) * (9 + 2 * MPC_MAX_N) * S));
+  double *d_state = h->d_in, *d_coef = d_state + 6 * S, *d_ylo = d_coef + 5 * S, *d_yhi = d_ylo + S, *d_w = d_yhi + S;
+  double *d_o = h->d_out, *d_t = d_o + 9 * S;
+  hipStream_t s = h->stream;
+  for (int q = 0; q < 6; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_state + q * S, state + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
+  for (int q = 0; q < 5; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_coef + q * S, coeffs + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(d_ylo, yaw_lo, sizeof(double) * B, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(d_yhi, yaw_hi, sizeof(double) * B, hipMemcpyHostToDevice, s));
+  if (weights) for (int q = 0; q < MPC_NW; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_w + q * S, weights + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
+  int rc = mpc_solve_batch_device(h, B, S, d_state, d_coef, d_ylo, d_yhi, weights ? d_w : nullptr, d_o,
+                                  traj ? d_t : nullptr, h->d_status, h->d_iters, nullptr);
+  if (rc != MPC_OK) return rc;
+  for (int q = 0; q < 9; q++) MPC_HIP_CHECK(hipMemcpyAsync(out + q * ld, d_o + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));
+  if (traj) for (int q = 0; q < 2 * N; q++) MPC_HIP_CHECK(hipMemcpyAsync(traj + q * ld, d_t + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  if (iters) MPC_HIP_CHECK(hipMemcpyAsync(iters, h->d_iters, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipStreamSynchronize(s));
+  h->last_status = h->d_status; h->last_iters = h->d_iters;
+  return MPC_OK;
+}
+
+extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
+  if (!h || !st) return MPC_ERR_INVALID;
+  memset(st, 0, sizeof(*st));
+  st->batch = h->last_B;
+  if (h->last_B == 0 || !h->last_status) return MPC_OK;
+  MPC_HIP_CHECK(hipSetDevice(h->device));
+  MPC_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<int32_t> s(h->last_B), it(h->last_B);
+  MPC_HIP_CHECK(hipMemcpy(s.data(), h->last_status, sizeof(int32_t) * h->last_B, hipMemcpyDeviceToHost));
+  MPC_HIP_CHECK(hipMemcpy(it.data(), h->last_iters, sizeof(int32_t) * h->last_B, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < h->last_B; i++) {
+    switch (s[i]) {
+      case MPC_STATUS_SUCCESS: st->n_success++; break;
+      case MPC_STATUS_MAXITER: st->n_maxiter++; break;
+      case MPC_STATUS_LINESEARCH: st->n_linesearch++; break;
+      case MPC_STATUS_INFEASIBLE: st->n_infeasible++; break;
+      default: st->n_numeric++; break;
+    }
+    st->iter_sum += it[i];
+    if (it[i] > st->iter_max) st->iter_max = it[i];
+  }
+  if (h->timed) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;
+  }
+  return MPC_OK;
+}

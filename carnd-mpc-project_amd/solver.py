@@ -1,0 +1,108 @@
+"""BatchedMPC: thin Python handle over the C ABI (include/mpc_amd.h).
+
+Mirrors, for a batch, what ``MPC::solve(state, target_velocity, x_traj, y_traj)``
+returns in the reference (src/control/MPC.cpp:183-325): a 9-vector per instance
+``{x1,y1,psi1,v1,cte1,epsi1,delta0,a0,cost}`` plus the optional N-point (x,y)
+trajectory, and a status per instance (the reference only prints it).
+torch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import MpcBatchStats, MpcParams, check, library
+
+
+class BatchedMPC:
+    def __init__(self, params: MpcParams, max_batch: int, device: int = -1):
+        self.params = params.copy()
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        check(library().mpc_create(C.byref(self.params), int(device), self.max_batch, C.byref(self._h)), "mpc_create")
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            library().mpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def N(self):
+        return self.params.N
+
+    def set_params(self, params: MpcParams):
+        check(library().mpc_set_params(self._h, C.byref(params)), "mpc_set_params")
+        self.params = params.copy()
+
+    # -- device path (torch tensors resident in HBM) -------------------------
+    def alloc_outputs(self, B, device, want_traj=False):
+        import torch
+        out = {
+            "out": torch.empty((_abi.NOUT, B), dtype=torch.float64, device=device),
+            "status": torch.empty((B,), dtype=torch.int32, device=device),
+            "iters": torch.empty((B,), dtype=torch.int32, device=device),
+            "traj": torch.empty((2 * self.N, B), dtype=torch.float64, device=device) if want_traj else None,
+        }
+        return out
+
+    def solve_torch(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False, outputs=None, stream=None):
+        """state [6,B], coeffs [5,B], yaw_lo/hi [B], weights [12,B] or None: float64 CUDA tensors.
+        Asynchronous on ``stream`` (default: torch's current stream). Returns the dict of output tensors."""
+        import torch
+        B = state.shape[1]
+        for name, t, rows in (("state", state, 6), ("coeffs", coeffs, 5)):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape != (rows, B):
+                raise ValueError("%s must be a contiguous float64 CUDA tensor of shape (%d, B)" % (name, rows))
+        for name, t in (("yaw_lo", yaw_lo), ("yaw_hi", yaw_hi)):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape != (B,):
+                raise ValueError("%s must be a contiguous float64 CUDA tensor of shape (B,)" % name)
+        if weights is not None and (weights.dtype != torch.float64 or not weights.is_cuda or
+                                    not weights.is_contiguous() or weights.shape != (_abi.NW, B)):
+            raise ValueError("weights must be a contiguous float64 CUDA tensor of shape (12, B)")
+        if outputs is None:
+            outputs = self.alloc_outputs(B, state.device, want_traj)
+        s = stream if stream is not None else torch.cuda.current_stream(state.device)
+        traj = outputs.get("traj")
+        check(library().mpc_solve_batch_device(
+            self._h, B, B, state.data_ptr(), coeffs.data_ptr(), yaw_lo.data_ptr(), yaw_hi.data_ptr(),
+            weights.data_ptr() if weights is not None else None, outputs["out"].data_ptr(),
+            traj.data_ptr() if traj is not None else None, outputs["status"].data_ptr(),
+            outputs["iters"].data_ptr(), C.c_void_p(s.cuda_stream)), "mpc_solve_batch_device")
+        return outputs
+
+    # -- host path (numpy arrays; copies through PCIe) ------------------------
+    def solve_numpy(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False):
+        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        state, coeffs, yaw_lo, yaw_hi = f(state), f(coeffs), f(yaw_lo), f(yaw_hi)
+        B = state.shape[1]
+        assert state.shape == (6, B) and coeffs.shape == (5, B) and yaw_lo.shape == (B,) and yaw_hi.shape == (B,)
+        if weights is not None:
+            weights = f(weights)
+            assert weights.shape == (_abi.NW, B)
+        out = np.empty((_abi.NOUT, B)); status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        traj = np.empty((2 * self.N, B)) if want_traj else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        check(library().mpc_solve_batch_host(self._h, B, B, p(state), p(coeffs), p(yaw_lo), p(yaw_hi), p(weights),
+                                             p(out), p(traj), p(status), p(iters)), "mpc_solve_batch_host")
+        return {"out": out, "status": status, "iters": iters, "traj": traj}
+
+    def synchronize(self):
+        check(library().mpc_synchronize(self._h), "mpc_synchronize")
+
+    def stats(self) -> MpcBatchStats:
+        st = MpcBatchStats()
+        check(library().mpc_get_stats(self._h, C.byref(st)), "mpc_get_stats")
+        return st

@@ -1,0 +1,160 @@
+/*
+ * mpc_amd.h -- C ABI of the MI355X-native batched MPC solver.
+ *
+ * This is the drop-in boundary for ONE path of dr-tony-lin/CarND-MPC-Project:
+ * MPC::solve() + FG_eval (src/control/MPC.cpp:14-155, 183-325), i.e. the call
+ *     CppAD::ipopt::solve<Dvector, FG_eval>(options, vars, vars_lowerbound,
+ *         vars_upperbound, constraints_lowerbound, constraints_upperbound,
+ *         fg_eval, solution);                      // MPC.cpp:290-292
+ * together with the set-up before it (MPC.cpp:204-281) and the unpacking after
+ * it (MPC.cpp:306-324), for B independent problem instances at once.
+ *
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross this
+ * boundary (integer return codes + a per-instance status array, mirroring the
+ * reference's "print and still return solution.x" behaviour, MPC.cpp:295-303).
+ * There is no CPU fallback: every entry point that computes needs a gfx950
+ * device and fails with MPC_ERR_NO_DEVICE / MPC_ERR_HIP otherwise.
+ *
+ * Batch layout is struct-of-arrays ("quantity-major", like the reference's own
+ * decision vector, MPC.cpp:56-63): element (q, i) of an array with Q rows is at
+ * [q * ld + i], ld >= B, so that consecutive instances are consecutive in
+ * memory and a wavefront's loads coalesce.
+ */
+#ifndef MPC_AMD_H
+#define MPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_ABI_VERSION 1
+#define MPC_MAX_TABLE 16
+#define MPC_NW 12      /* Config::weights entries read by FG_eval (Config.h:14-61) */
+#define MPC_NCOEF 5    /* road polynomial, zero padded: fit order is 2..4 (RoadGeometry.cpp:26-34) */
+#define MPC_NSTATE 6   /* x, y, psi, v, cte, epsi (MPC.cpp:213-218) */
+#define MPC_NOUT 9     /* x1,y1,psi1,v1,cte1,epsi1,delta0,a0,cost (MPC.cpp:322-324) */
+#define MPC_MAX_N 64   /* largest horizon the kernels are sized for */
+
+/* return codes */
+enum {
+  MPC_OK = 0,
+  MPC_ERR_INVALID = -1,     /* bad argument (NULL, N out of range, ld < B ...) */
+  MPC_ERR_NO_DEVICE = -2,   /* no gfx950 device / HIP runtime unavailable */
+  MPC_ERR_HIP = -3,         /* a HIP call failed; see mpc_last_error() */
+  MPC_ERR_UNSUPPORTED = -4, /* e.g. branch_mode LIVE or precision f32 not built */
+  MPC_ERR_IO = -5           /* config file unreadable / malformed */
+};
+
+/* per-instance status, modelled on CppAD::ipopt::solve_result<>::status_type
+ * (MPC.cpp:295): 0 is the only value the reference treats as "ok". */
+enum {
+  MPC_STATUS_SUCCESS = 0,
+  MPC_STATUS_MAXITER = 1,
+  MPC_STATUS_LINESEARCH = 2,   /* step length fell below alpha_min (IPOPT: restoration) */
+  MPC_STATUS_INFEASIBLE = 3,   /* initial state outside its own bounds (MPC.cpp:229-239 vs :269-281) */
+  MPC_STATUS_NUMERIC = 4       /* NaN/Inf met */
+};
+
+enum { MPC_BRANCH_FROZEN = 0, MPC_BRANCH_LIVE = 1 };
+enum { MPC_PRECISION_F64 = 0, MPC_PRECISION_F32 = 1 };
+
+/* Everything the reference reads from `struct Config` statics on this path
+ * (src/utils/Config.h:66-177) AFTER Config::load() has applied its unit
+ * conversions and table rescaling (src/utils/Config.cpp:31-87).  Passed by
+ * value per batch: no global state, unlike the reference's mutable Config. */
+typedef struct MpcParams {
+  int32_t abi_version;       /* MPC_ABI_VERSION */
+  int32_t N;                 /* Config::N,  3..MPC_MAX_N */
+  double dt;                 /* Config::dt */
+  double Lf;                 /* Config::Lf */
+  double weights[MPC_NW];    /* Config::weights[0..11] */
+  double cte_panic;          /* Config::ctePanic */
+  double epsi_panic;         /* Config::epsiPanic */
+  double max_steering;       /* rad  (bounds, MPC.cpp:248-251) */
+  double max_acceleration;   /* m/s2 (MPC.cpp:254-257) */
+  double max_deceleration;   /* m/s2, negative */
+  double max_speed;          /* m/s  (MPC.cpp:236-239) */
+  int32_t n_steers, n_steer_speeds;          /* Vehicle::computeSpeedTarget tables */
+  double steers[MPC_MAX_TABLE];
+  double steer_speeds[MPC_MAX_TABLE];
+  /* used only by the run() pre/post-processing entry points */
+  int32_t n_yaw_changes, n_yaw_change_speeds;
+  double yaw_changes[MPC_MAX_TABLE];
+  double yaw_change_speeds[MPC_MAX_TABLE];
+  int32_t max_fit_order;     /* Config::maxFitOrder */
+  int32_t latency_ms;        /* Config::latency */
+  double max_fit_error;      /* Config::maxFitError */
+  double lookahead;          /* Config::lookahead = latency * 1e-3 */
+  double steer_adj_thresh;   /* Config::steerAdjustmentThresh */
+  double steer_adj_ratio;    /* Config::steerAdjustmentRatio (clamped to [0,0.1]) */
+  double ipopt_timeout;      /* Config::ipoptTimeout: carried, not used (we cap iterations) */
+  /* solver controls (the reference's IPOPT option string, MPC.cpp:160-179, plus
+   * the IPOPT defaults it leaves untouched) */
+  int32_t branch_mode;       /* MPC_BRANCH_FROZEN: CppAD tape recorded once at the start point */
+  int32_t precision;         /* MPC_PRECISION_F64 */
+  int32_t max_iter;          /* IPOPT default 3000; default here 200 */
+  int32_t reserved0;
+  double tol;                /* IPOPT "tol", default 1e-8 */
+} MpcParams;
+
+typedef struct MpcHandle MpcHandle;
+
+/* Aggregate statistics of the last batch (diagnostics for bench/tests). */
+typedef struct MpcBatchStats {
+  int64_t batch;
+  int64_t n_success, n_maxiter, n_linesearch, n_infeasible, n_numeric;
+  int64_t iter_sum;          /* sum of interior-point iterations over the batch */
+  int32_t iter_max;
+  int32_t reserved;
+  double kernel_ms;          /* hipEvent time of the solve kernel, on its own stream */
+} MpcBatchStats;
+
+/* ---- parameters ---------------------------------------------------------- */
+/* Compiled-in defaults of the reference, src/utils/Config.cpp:5-29. */
+int mpc_params_default(MpcParams *p);
+/* Config::load(fileName), src/utils/Config.cpp:31-87, same JSON keys. */
+int mpc_params_load_json(const char *path, MpcParams *p);
+
+/* ---- lifetime -------------------------------------------------------------- */
+/* device < 0: current HIP device.  max_batch sizes the device workspace. */
+int mpc_create(const MpcParams *p, int device, int64_t max_batch, MpcHandle **out);
+int mpc_set_params(MpcHandle *h, const MpcParams *p);
+void mpc_destroy(MpcHandle *h);
+const char *mpc_last_error(void);
+int mpc_abi_version(void);
+
+/* ---- the hot path ---------------------------------------------------------- */
+/*
+ * Solve B instances; all pointers are DEVICE pointers (HBM resident):
+ *   state  [6][ld]   initial state per instance            (MPC.cpp:213-218)
+ *   coeffs [5][ld]   road polynomial c0..c4, zero padded   (RoadGeometry, MPC.cpp:151-152)
+ *   yaw_lo [ld], yaw_hi [ld]   psi bounds = Config::yawLow/yawHigh as MPC::run
+ *                    sets them just before solve()          (MPC.cpp:345-352, 229-232)
+ *   weights[12][ld]  per-instance Config::weights, or NULL to use p->weights
+ *   out    [9][ld]   the vector MPC::solve returns          (MPC.cpp:322-324)
+ *   traj   [2N][ld]  x[0..N) then y[0..N) of the solution, or NULL (MPC.cpp:306-311)
+ *   status [ld]      per-instance MPC_STATUS_*
+ *   iters  [ld]      per-instance iteration count, or NULL
+ * stream: a hipStream_t (as void*), NULL = the handle's own stream.  The call
+ * is asynchronous with respect to the host; use mpc_synchronize() or the
+ * caller's stream to wait.
+ */
+int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                           const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                           const double *weights, double *out, double *traj, int32_t *status,
+                           int32_t *iters, void *stream);
+/* Same, host pointers: copies in, launches, copies out, synchronises. */
+int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                         const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                         const double *weights, double *out, double *traj, int32_t *status,
+                         int32_t *iters);
+int mpc_synchronize(MpcHandle *h);
+/* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
+int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_AMD_H */

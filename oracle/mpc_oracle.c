@@ -887,11 +887,13 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
       if (tiny) { accepted = 1; ftype = 1; break; }
       if (theta_t < theta_max && !filter_rejects(flt, theta_t, phi_t)) {
         int sw = dphi < 0 && alpha * pow(-dphi, s_phi) > delta_sw * pow(theta_k, s_theta);
+        int armijo = phi_t - phi_k - eps_phi <= eta_phi * alpha * dphi;
         if (theta_k <= theta_min && sw) {
-          if (phi_t - phi_k - eps_phi <= eta_phi * alpha * dphi) { accepted = 1; ftype = 1; }
+          if (armijo) accepted = 1;
         } else if (theta_t <= (1 - gamma_theta) * theta_k || phi_t - phi_k - eps_phi <= -gamma_phi * theta_k) {
-          accepted = 1; ftype = 0;
+          accepted = 1;
         }
+        ftype = sw && armijo;   /* filter is augmented unless both hold (W&B step A-7) */
       }
       if (accepted) break;
       alpha *= 0.5; info->n_backtracks++;
