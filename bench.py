@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC solves/sec of the batched HIP path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (the batched replacement of MPC::solve(), src/control/MPC.cpp:183-325)
+over one batch of synthetic inputs that are ALREADY RESIDENT IN HBM.  Workload at every N: BASELINE.json
+configs[2] per GPU -- 65 536 lake-track states with 100 ms latency compensation, N=10, dt=0.1,
+config-fast.json, fp64, trajectories requested -- i.e. weak scaling: each rank solves its own 65 536
+instances (different PRNG streams), then the per-instance results are gathered once with a single
+all_gather (RCCL) inside the timed step.  Rank 0 prints ONE JSON line.
+
+roofline: bound "hbm" with ALGORITHMIC bytes = 336 B/solve (in 104 + out 72 +
+trajectory 160) x solves per launch / the solve kernel's average launch duration measured live with HIP
+events on the launch stream.  The path is fp64-VALU/latency bound, so the HBM fraction is tiny by
+construction; `fp64_valu_frac` next to it prices the same launches against the 78.6 TFLOP/s vector peak
+using the algorithmic flop count of section 8d (2.5 kflop x stages x iterations).
+cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port"), one thread, a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_SOLVE = 8 * (6 + 5 + 2) + 8 * 9 + 8 * 2 * 10   # 104 in + 72 out + 160 trajectory = 336 (N=10)
+HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6
+KFLOP_PER_STAGE_ITER = 2.5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--config", default="config-fast.json")
+    ap.add_argument("--no-traj", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as G
+    pkg = G.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    golden = os.path.join(ROOT, "tests", "golden")
+    params = pkg.params_from_json(os.path.join(golden, args.config))
+    wp = pkg.scenarios.load_waypoints(os.path.join(golden, "lake_track_waypoints.csv"))
+    B = args.batch
+    want_traj = not args.no_traj
+    # weak scaling: every rank draws its own instances (rank-specific PRNG stream)
+    batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_state, d_coef, d_ylo, d_yhi = t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"])
+    mpc = pkg.BatchedMPC(params, B, device=local_rank)
+    outs = mpc.alloc_outputs(B, dev, want_traj)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, outputs=outs)     # async on torch's current stream
+        if dist is not None:
+            gathered = pkg.sharding.gather_results(outs, B * world, dist)  # the path's only collective
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    # HIP events on the stream the kernel is launched on (= torch's current stream, passed to the C ABI)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, outputs=outs)
+        ev[i][1].record()
+        if dist is not None:
+            gathered = pkg.sharding.gather_results(outs, B * world, dist)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms_avg = float(np.mean(kernel_ms))
+    stats = mpc.stats()
+    status = outs["status"].cpu().numpy()
+    out_np = outs["out"].cpu().numpy()
+
+    if rank != 0:
+        mpc.close()
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    total_solves = B * world * args.steps
+    value = total_solves / elapsed
+    mean_iters = stats.iter_sum / max(1, stats.batch)
+    stages = params.N - 1
+    res = {
+        "metric": "MPC solves/sec (batch) at N=10 dt=0.1",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: %d lake-track states per GPU, 100 ms latency compensation, "
+                               "N=%d dt=%g, %s, trajectories %s" % (B, params.N, params.dt, args.config, "on" if want_traj else "off"),
+                   "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
+                   "parallelism": "%d independent shard(s), one all_gather of results" % world,
+                   "branch_mode": "frozen", "tol": params.tol, "max_iter": params.max_iter},
+        "converged_fraction": float((status == 0).mean()),
+        "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
+        "mean_iterations": mean_iters, "max_iterations": int(stats.iter_max),
+    }
+    algo_bytes = (ALGO_BYTES_PER_SOLVE if want_traj else 176) * B
+    achieved_gbs = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            pj = json.load(open(pmc))
+            if pj.get("batch") == B and pj.get("config") == args.config:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                       "kernel": "mpc_solve_kernel", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
+                       "algorithmic_bytes_per_launch": algo_bytes,
+                       "note": "fp64-VALU/latency-bound path: HBM fraction is small by construction (SURVEY.md 8d)",
+                       "fp64_valu_tflops": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (kernel_ms_avg * 1e-3) / 1e12,
+                       "fp64_valu_frac": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (kernel_ms_avg * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+
+    if world == 1 and not args.no_cpu_baseline:
+        # the checker, timed as the CPU baseline: oracle = plain-C restatement of the reference algorithm
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cfg = O.load_config(args.config)
+        n_done, worst_steer, worst_acc, t_cpu0 = 0, 0.0, 0.0, time.perf_counter()
+        t_solve = 0.0
+        while n_done < min(B, 4096) and (time.perf_counter() - t_cpu0) < args.cpu_seconds:
+            i = n_done
+            cfg.yaw_low, cfg.yaw_high = float(batch["yaw_lo"][i]), float(batch["yaw_hi"][i])
+            ts = time.perf_counter()
+            st, o9, _, _, _ = O.mpc_solve(cfg, batch["state"][:, i], batch["coeffs"][:, i])
+            t_solve += time.perf_counter() - ts
+            if st == 0 and status[i] == 0:
+                worst_steer = max(worst_steer, abs(o9[6] - out_np[6, i]))
+                worst_acc = max(worst_acc, abs(o9[7] - out_np[7, i]))
+            n_done += 1
+        res["cpu_baseline"] = {"value": n_done / t_solve, "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": "first %d instances of the same batch, oracle/mpc_oracle.c (dense IPOPT-style "
+                                         "interior point), 1 thread of %d host cores" % (n_done, os.cpu_count() or 0)}
+        res["max_abs_dsteer_vs_oracle"] = worst_steer
+        res["max_abs_daccel_vs_oracle"] = worst_acc
+        res["parity_sample"] = n_done
+    print(json.dumps(res))
+    mpc.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

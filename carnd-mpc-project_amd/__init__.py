@@ -14,6 +14,7 @@ from ._abi import (MpcParams, MpcBatchStats, MpcError, library, library_path, bu
                    params_default, params_from_json, STATUS_NAMES)
 from .solver import BatchedMPC
 from . import scenarios
+from . import sharding
 
 __all__ = ["MpcParams", "MpcBatchStats", "MpcError", "library", "library_path", "build_library",
-           "params_default", "params_from_json", "BatchedMPC", "scenarios", "STATUS_NAMES"]
+           "params_default", "params_from_json", "BatchedMPC", "scenarios", "sharding", "STATUS_NAMES"]

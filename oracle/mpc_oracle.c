@@ -980,6 +980,16 @@ int orc_mpc_solve(const OrcConfig *cfg, const OrcSolveOptions *opt_in, const dou
     free(x0); free(prev);
   } else {
     status = ipm_solve(&P, &opt, xi, x, NULL, &info);
+    if ((status == ORC_RESTORATION_FAILURE || status == ORC_MAXITER_EXCEEDED) && opt.lam_init_ls) {
+      /* IPOPT would switch to its feasibility-restoration phase here, which this oracle does not
+       * restate.  Stand-in: restart from the same start point with zero equality multipliers
+       * (what IPOPT itself falls back to when the least-squares estimate is rejected). */
+      OrcSolveOptions o2 = opt; o2.lam_init_ls = 0;
+      OrcSolveInfo i2;
+      int s2 = ipm_solve(&P, &o2, xi, x, NULL, &i2);
+      i2.iterations += info.iterations; i2.n_regularised += info.n_regularised; i2.n_backtracks += info.n_backtracks;
+      info = i2; status = s2;
+    }
   }
   if (traj_x && traj_y) for (int i = 0; i < I.N; i++) { traj_x[i] = x[I.x + i]; traj_y[i] = x[I.y + i]; }  /* :306-311 */
   out9[0] = x[I.x + 1]; out9[1] = x[I.y + 1]; out9[2] = x[I.psi + 1]; out9[3] = x[I.v + 1];               /* :322-324 */

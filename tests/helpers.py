@@ -1,0 +1,81 @@
+"""Shared test helpers (test infrastructure)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the reference's own demo scenario, src/test.cpp:45-50
+TEST_CPP = dict(
+    ptsx=[-145.1165, -158.3417, -164.3164, -169.3365, -175.4917, -176.9617],
+    ptsy=[4.339378, -17.42898, -30.18062, -42.84062, -66.52898, -76.85062],
+    pose=[-146.7283, 1.660802, 4.125825, 26.6806, 0.0, 0.0])
+
+# stated fp64 tolerances (SURVEY.md section 8d / BASELINE.md section 4)
+TOL_STEER = 1e-6   # rad, delta0
+TOL_ACCEL = 1e-6   # m/s^2, a0
+TOL_TRAJ = 1e-5    # m, predicted trajectory points / step-1 state
+TOL_COST_REL = 1e-7
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def twin_solve(twin, params, batch, weights=None, want_traj=True):
+    """Run the TEST-ONLY host twin on a batch dict (state, coeffs, yaw_lo, yaw_hi)."""
+    st = np.ascontiguousarray(batch["state"], dtype=np.float64)
+    cf = np.ascontiguousarray(batch["coeffs"], dtype=np.float64)
+    yl = np.ascontiguousarray(batch["yaw_lo"], dtype=np.float64)
+    yh = np.ascontiguousarray(batch["yaw_hi"], dtype=np.float64)
+    B = st.shape[1]
+    out = np.zeros((9, B)); traj = np.zeros((2 * params.N, B)) if want_traj else None
+    status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+    w = np.ascontiguousarray(weights, dtype=np.float64) if weights is not None else None
+    rc = twin.mpc_host_twin_solve(C.byref(params), C.c_int64(B), C.c_int64(B), vp(st), vp(cf), vp(yl), vp(yh), vp(w),
+                                  vp(out), vp(traj), vp(status), vp(iters))
+    assert rc == 0
+    return {"out": out, "traj": traj, "status": status, "iters": iters}
+
+
+def oracle_solve_batch(cfg, batch, idx, opt=None, weights=None):
+    """Oracle MPC::solve for the selected instances -> dict of arrays (out [9,n], traj [2N,n], status, iters)."""
+    n = len(idx)
+    out = np.zeros((9, n)); traj = np.zeros((2 * cfg.N, n)); status = np.zeros(n, dtype=np.int32)
+    iters = np.zeros(n, dtype=np.int32)
+    for j, i in enumerate(idx):
+        cfg.yaw_low = float(batch["yaw_lo"][i]); cfg.yaw_high = float(batch["yaw_hi"][i])
+        if weights is not None:
+            for q in range(12):
+                cfg.weights[q] = float(weights[q, i])
+        st, o9, tx, ty, info = O.mpc_solve(cfg, batch["state"][:, i], batch["coeffs"][:, i], opt)
+        out[:, j] = o9; traj[:cfg.N, j] = tx; traj[cfg.N:, j] = ty; status[j] = st; iters[j] = info.iterations
+    return {"out": out, "traj": traj, "status": status, "iters": iters}
+
+
+def assert_parity(got_out, ref_out, got_traj=None, ref_traj=None, what=""):
+    d_state = np.max(np.abs(got_out[:6] - ref_out[:6]))
+    d_steer = np.max(np.abs(got_out[6] - ref_out[6]))
+    d_acc = np.max(np.abs(got_out[7] - ref_out[7]))
+    d_cost = np.max(np.abs(got_out[8] - ref_out[8]) / np.maximum(1.0, np.abs(ref_out[8])))
+    assert d_steer <= TOL_STEER, "%s max |d steer| = %g rad" % (what, d_steer)
+    assert d_acc <= TOL_ACCEL, "%s max |d accel| = %g" % (what, d_acc)
+    assert d_state <= TOL_TRAJ, "%s max |d step-1 state| = %g" % (what, d_state)
+    assert d_cost <= TOL_COST_REL, "%s max rel |d cost| = %g" % (what, d_cost)
+    if got_traj is not None and ref_traj is not None:
+        d_t = np.max(np.abs(got_traj - ref_traj))
+        assert d_t <= TOL_TRAJ, "%s max |d trajectory| = %g m" % (what, d_t)
+    return d_steer, d_acc, d_state
+
+
+def sol_from_outputs(N, state, traj, out, full=None):
+    """Not every output carries the full decision vector; helper kept for KKT checks on oracle solutions."""
+    return full
+
+
+def load_golden(name):
+    return json.load(open(os.path.join(ROOT, "tests", "golden", name)))

@@ -1,0 +1,87 @@
+"""The C ABI (include/mpc_amd.h): the library loads, exports every declared symbol, parameter loading
+matches the oracle's Config::load restatement, and compute entry points FAIL LOUDLY without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from carnd_mpc_project_amd import _abi
+    lib = pkg.library()
+    header = open(os.path.join(_abi.ROOT, "include", "mpc_amd.h")).read()
+    declared = set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", header))
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mpc_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_layout_matches_header(pkg):
+    """sizeof(MpcParams) seen by ctypes == the C compiler's (via a tiny compiled probe)."""
+    import subprocess, tempfile
+    from carnd_mpc_project_amd import _abi
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "mpc_amd.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(MpcParams), offsetof(MpcParams, tol), offsetof(MpcParams, steers), sizeof(MpcBatchStats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(_abi.ROOT, "include"), "-o", os.path.join(d, "p"), os.path.join(d, "p.c")])
+        out = subprocess.check_output([os.path.join(d, "p")]).split()
+    assert int(out[0]) == C.sizeof(pkg.MpcParams)
+    assert int(out[1]) == pkg.MpcParams.tol.offset
+    assert int(out[2]) == pkg.MpcParams.steers.offset
+    assert int(out[3]) == C.sizeof(pkg.MpcBatchStats)
+
+
+@pytest.mark.parametrize("name", ["config-stable.json", "config-fast.json", "config-no-latency.json"])
+def test_params_from_json_match_oracle_config(pkg, golden_dir, name):
+    p = pkg.params_from_json(os.path.join(golden_dir, name))
+    c = O.load_config(name)
+    assert (p.N, p.dt, p.Lf) == (c.N, c.dt, c.Lf)
+    for f_abi, f_orc in (("max_steering", "max_steering"), ("max_acceleration", "max_acceleration"),
+                         ("max_deceleration", "max_deceleration"), ("max_speed", "max_speed"),
+                         ("cte_panic", "cte_panic"), ("epsi_panic", "epsi_panic"), ("lookahead", "lookahead"),
+                         ("max_fit_error", "max_fit_error"), ("steer_adj_thresh", "steer_adj_thresh"),
+                         ("steer_adj_ratio", "steer_adj_ratio")):
+        assert getattr(p, f_abi) == getattr(c, f_orc), f_abi
+    assert p.max_fit_order == c.max_fit_order and p.latency_ms == c.latency
+    assert list(p.weights) == list(c.weights)[:12]
+    assert (p.n_steers, p.n_steer_speeds, p.n_yaw_changes, p.n_yaw_change_speeds) == (c.n_steers, c.n_steer_speeds, c.n_yaw_changes, c.n_yaw_change_speeds)
+    assert list(p.steers)[:p.n_steers] == list(c.steers)[:c.n_steers]
+    assert list(p.steer_speeds)[:p.n_steer_speeds] == list(c.steer_speeds)[:c.n_steer_speeds]
+    assert list(p.yaw_change_speeds)[:p.n_yaw_change_speeds] == list(c.yaw_change_speeds)[:c.n_yaw_change_speeds]
+    assert p.branch_mode == 0 and p.precision == 0 and p.tol == 1e-8
+
+
+def test_params_errors(pkg, tmp_path):
+    with pytest.raises(pkg.MpcError):
+        pkg.params_from_json(str(tmp_path / "missing.json"))
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"N": 10, "dt": 0.1, "weights": [1, 2, 3]}')     # Config.cpp:61 assert(weights.size() > 11)
+    with pytest.raises(pkg.MpcError):
+        pkg.params_from_json(str(bad))
+    d = pkg.params_default()                                          # Config.cpp:5-29
+    assert d.N == 25 and d.dt == 0.025 and d.n_steers == 3 and d.n_steer_speeds == 4
+
+
+def test_no_cpu_fallback_without_gpu(pkg, golden_dir):
+    """On a box without a gfx950 device the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    p = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    with pytest.raises(pkg.MpcError) as e:
+        pkg.BatchedMPC(p, 16)
+    assert "NO_DEVICE" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_invalid_params_rejected(pkg, golden_dir):
+    p = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    h = C.c_void_p()
+    for field, val in (("N", 2), ("N", 65), ("abi_version", 99), ("branch_mode", 1), ("precision", 1), ("max_iter", 0)):
+        q = p.copy(); setattr(q, field, val)
+        rc = pkg.library().mpc_create(C.byref(q), 0, 16, C.byref(h))
+        assert rc in (-1, -4), (field, rc)

@@ -1,0 +1,216 @@
+"""Parity tests proper: the HIP path, called through the C ABI (include/mpc_amd.h), against the oracle.
+
+Tolerances (fp64, stated in BASELINE.md section 4 / SURVEY.md section 8d): |d delta0| <= 1e-6 rad,
+|d a0| <= 1e-6 m/s^2, step-1 state and trajectory points <= 1e-5 m, cost <= 1e-7 relative.
+Nothing here reads /root/reference.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import TEST_CPP, assert_parity, load_golden, oracle_solve_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+
+def gpu_solve(pkg, params, batch, dev, weights=None, want_traj=True, mpc=None):
+    import torch
+    B = batch["state"].shape[1]
+    own = mpc is None
+    if own:
+        mpc = pkg.BatchedMPC(params, max(B, 1), device=0)
+    r = mpc.solve_torch(_t(batch["state"], dev), _t(batch["coeffs"], dev), _t(batch["yaw_lo"], dev),
+                        _t(batch["yaw_hi"], dev), weights=_t(weights, dev) if weights is not None else None,
+                        want_traj=want_traj)
+    torch.cuda.synchronize()
+    out = {k: (v.cpu().numpy() if v is not None else None) for k, v in r.items()}
+    if own:
+        mpc.close()
+    return out
+
+
+def test_native_library_is_loaded(pkg):
+    """The HIP extension is what runs: it is mapped into this process and there is no other solver."""
+    pkg.library()
+    maps = open("/proc/self/maps").read()
+    assert "libmpc_amd.so" in maps
+
+
+def test_test_cpp_scenario_host_api(pkg, golden_dir):
+    """BASELINE.json configs[0]: single state through run() preprocessing -> solve(), B = 1, host pointers."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    cfg = O.load_config("config-stable.json")
+    pre, _, _ = O.run_pre(cfg, TEST_CPP["pose"], TEST_CPP["ptsx"], TEST_CPP["ptsy"])
+    coef = np.zeros((5, 1)); coef[:pre.nc, 0] = list(pre.coef)[:pre.nc]
+    b = {"state": np.array(list(pre.state)).reshape(6, 1), "coeffs": coef,
+         "yaw_lo": np.array([pre.yaw_low]), "yaw_hi": np.array([pre.yaw_high])}
+    with pkg.BatchedMPC(params, 1, device=0) as mpc:
+        r = mpc.solve_numpy(b["state"], b["coeffs"], b["yaw_lo"], b["yaw_hi"], want_traj=True)
+    assert r["status"][0] == 0
+    assert r["out"][6, 0] == pytest.approx(0.0024133755, abs=5e-9)
+    assert r["out"][7, 0] == pytest.approx(4.47038889, abs=1e-7)
+    assert r["out"][8, 0] == pytest.approx(6243.44368073, abs=1e-5)
+    ref = oracle_solve_batch(cfg, b, [0])
+    assert_parity(r["out"], ref["out"], r["traj"], ref["traj"], "test.cpp")
+
+
+@pytest.mark.parametrize("config,kind,B,n_ref", [("config-stable.json", "straight", 4096, 256),
+                                                  ("config-fast.json", "lake", 2048, 256),
+                                                  ("config-no-latency.json", "lake", 512, 128)])
+def test_batch_matches_oracle(pkg, golden_dir, waypoints, torch_dev, config, kind, B, n_ref):
+    """BASELINE.json configs[1] (4096 straight-line offsets, config-stable) and lake-track batches."""
+    params = pkg.params_from_json(os.path.join(golden_dir, config))
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=41) if kind == "lake" else pkg.scenarios.straight_line_batch(B, params)
+    r = gpu_solve(pkg, params, b, torch_dev)
+    assert (r["status"] == 0).all(), np.bincount(r["status"])
+    idx = np.random.default_rng(0).choice(B, n_ref, replace=False)
+    ref = oracle_solve_batch(O.load_config(config), b, idx)
+    assert (ref["status"] == 0).all()
+    assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "%s/%s" % (config, kind))
+
+
+def test_long_horizon_matches_oracle(pkg, golden_dir, waypoints, torch_dev):
+    """BASELINE.json configs[3] at test size: N=25, dt=0.05, fp64."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
+    B = 256
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=42)
+    r = gpu_solve(pkg, params, b, torch_dev)
+    assert (r["status"] == 0).all()
+    idx = range(0, B, 4)
+    ref = oracle_solve_batch(O.load_config("config-stable.json", N=25, dt=0.05), b, idx)
+    assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25")
+
+
+def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev):
+    """BASELINE.json configs[4] at test size (fp64): per-instance weight sweep."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 512
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=43)
+    w = pkg.scenarios.weight_sweep(B, params, seed=44)
+    r = gpu_solve(pkg, params, b, torch_dev, weights=w)
+    assert (r["status"] == 0).all()
+    idx = list(range(0, B, 4))
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
+    ok = ref["status"] == 0
+    assert ok.sum() >= len(idx) - 2
+    assert_parity(r["out"][:, idx][:, ok], ref["out"][:, ok], r["traj"][:, idx][:, ok], ref["traj"][:, ok], "weights")
+    w2 = w.copy(); w2[6] = 777.0              # acceleration weight: no effect under the frozen tape (F3a)
+    r2 = gpu_solve(pkg, params, b, torch_dev, weights=w2)
+    assert np.array_equal(r2["out"], r["out"])
+
+
+def test_scipy_goldens(pkg, golden_dir, torch_dev):
+    gold = load_golden("scipy_cross_solve.json")
+    for cfgname in ("config-stable.json", "config-fast.json"):
+        cases = [c for c in gold["cases"] if c["config"] == cfgname]
+        params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+        b = {"state": np.array([c["state"] for c in cases]).T.copy(), "coeffs": np.array([c["coef"] for c in cases]).T.copy(),
+             "yaw_lo": np.array([c["yaw_lo"] for c in cases]), "yaw_hi": np.array([c["yaw_hi"] for c in cases])}
+        r = gpu_solve(pkg, params, b, torch_dev)
+        assert (r["status"] == 0).all()
+        ref = np.array([c["out9"] for c in cases]).T
+        assert np.max(np.abs(r["out"][6] - ref[6])) < 2e-6
+        assert np.max(np.abs(r["out"][7] - ref[7])) < 2e-6
+        assert np.max(np.abs(r["out"][:6] - ref[:6])) < 2e-5
+
+
+def test_full_size_properties(pkg, golden_dir, waypoints, torch_dev):
+    """BASELINE.json configs[2] at FULL size (65 536 lake-track states, config-fast.json): size-independent
+    properties + a random sample against the oracle."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 65536
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        st = mpc.stats()
+        assert st.n_success == B and st.batch == B
+        # idempotence / determinism: the same batch again is bitwise identical
+        r_again = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        assert np.array_equal(r_again["out"], r["out"]) and np.array_equal(r_again["traj"], r["traj"])
+        # permutation equivariance: instances are independent (bitwise)
+        perm = np.random.default_rng(1).permutation(B)
+        bp = {k: np.ascontiguousarray(b[k][..., perm]) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}
+        rp = gpu_solve(pkg, params, bp, torch_dev, mpc=mpc)
+        assert np.array_equal(rp["out"], r["out"][:, perm])
+        # a ragged sub-batch alone gives the same answers as inside the big batch
+        sub = {k: np.ascontiguousarray(b[k][..., 1000:1000 + 777]) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}
+        rs = gpu_solve(pkg, params, sub, torch_dev, mpc=mpc)
+        assert np.array_equal(rs["out"], r["out"][:, 1000:1777])
+    assert (r["status"] == 0).all()
+    out, s0, cf = r["out"], b["state"], b["coeffs"]
+    dt, Lf = params.dt, params.Lf
+    # bounds (MPC.cpp:229-257) hold at the returned point, up to the interior-point slack
+    assert np.all(np.abs(out[6]) <= params.max_steering + 1e-9)
+    assert np.all(out[7] <= params.max_acceleration + 1e-9) and np.all(out[7] >= params.max_deceleration - 1e-9)
+    assert np.all(out[2] >= b["yaw_lo"] - 1e-9) and np.all(out[2] <= b["yaw_hi"] + 1e-9)
+    # step-1 state satisfies the model equations of FG_eval (MPC.cpp:142-152) from the fixed initial state
+    v0 = s0[3]
+    f0 = cf[0]; fp0 = cf[1]                                     # x0 = 0
+    assert np.max(np.abs(out[0] - v0 * dt)) < 1e-8              # x1 = x0 + cos(0) v0 dt
+    assert np.max(np.abs(out[1])) < 1e-8                        # y1 = y0 + sin(0) v0 dt
+    assert np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-8
+    assert np.max(np.abs(out[3] - (v0 + out[7] * dt))) < 1e-8
+    assert np.max(np.abs(out[4] - (f0 + np.sin(s0[5]) * v0 * dt))) < 1e-8
+    assert np.max(np.abs(out[5] - (out[2] - np.arctan(fp0)))) < 1e-8
+    assert np.max(np.abs(r["traj"][1] - out[0])) == 0 and np.max(np.abs(r["traj"][0])) == 0
+    # mirror symmetry of the NLP: flip the road and the errors -> the steering flips
+    m = 4096
+    bm = {"state": s0[:, :m].copy(), "coeffs": -cf[:, :m], "yaw_lo": -b["yaw_hi"][:m], "yaw_hi": -b["yaw_lo"][:m]}
+    bm["state"][4] *= -1; bm["state"][5] *= -1
+    rm = gpu_solve(pkg, params, bm, torch_dev)
+    assert (rm["status"] == 0).all()
+    assert np.max(np.abs(rm["out"][6] + out[6, :m])) < 1e-6 and np.max(np.abs(rm["out"][7] - out[7, :m])) < 1e-6
+    # random sample against the oracle
+    idx = np.random.default_rng(2).choice(B, 256, replace=False)
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx)
+    assert (ref["status"] == 0).all()
+    assert_parity(out[:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "65536 sample")
+
+
+def test_host_and_device_entry_points_agree(pkg, golden_dir, waypoints, torch_dev):
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 333
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=45)
+    with pkg.BatchedMPC(params, 512, device=0) as mpc:
+        rd = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        rh = mpc.solve_numpy(b["state"], b["coeffs"], b["yaw_lo"], b["yaw_hi"], want_traj=True)
+    for k in ("out", "traj", "status", "iters"):
+        assert np.array_equal(rd[k], rh[k]), k
+
+
+def test_edge_cases_and_errors(pkg, golden_dir, torch_dev):
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    st = np.zeros((6, 4)); cf = np.zeros((5, 4))
+    st[3] = [60.0, 20.0, 20.0, 20.0]; st[2, 1] = 0.2; st[4, 3] = 0.7; cf[0, 3] = 0.7
+    b = {"state": st, "coeffs": cf, "yaw_lo": np.full(4, -0.1), "yaw_hi": np.full(4, 0.1)}
+    with pkg.BatchedMPC(params, 8, device=0) as mpc:
+        r = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        assert list(r["status"]) == [3, 3, 0, 0]           # infeasible fixed initial state is flagged, not hidden
+        assert abs(r["out"][6, 2]) < 1e-9 and r["out"][6, 3] > 0
+        # empty batch is a no-op
+        e = {"state": np.zeros((6, 0)), "coeffs": np.zeros((5, 0)), "yaw_lo": np.zeros(0), "yaw_hi": np.zeros(0)}
+        assert gpu_solve(pkg, params, e, torch_dev, mpc=mpc)["out"].shape == (9, 0)
+        # batch larger than the handle's workspace is refused
+        big = {"state": np.zeros((6, 9)), "coeffs": np.zeros((5, 9)), "yaw_lo": np.full(9, -0.1), "yaw_hi": np.full(9, 0.1)}
+        with pytest.raises(pkg.MpcError):
+            gpu_solve(pkg, params, big, torch_dev, mpc=mpc)
+        # iteration cap is honoured and reported per instance
+        q = params.copy(); q.max_iter = 3
+        mpc.set_params(q)
+        r3 = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        assert list(r3["status"][2:]) == [1, 1] and list(r3["iters"][2:]) == [3, 3]

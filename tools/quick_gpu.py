@@ -1,10 +1,10 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 pkg=G.load_package()
 G.smoke()
-params = pkg.params_from_json('tests/golden/config-fast.json')
-wp = pkg.scenarios.load_waypoints('tests/golden/lake_track_waypoints.csv')
+params = pkg.params_from_json(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+'/tests/golden/config-fast.json')
+wp = pkg.scenarios.load_waypoints(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+'/tests/golden/lake_track_waypoints.csv')
 for B in (4096, 65536):
     b = pkg.scenarios.lake_track_batch(B, params, wp)
     dev=torch.device('cuda:0'); t=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
