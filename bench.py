@@ -96,7 +96,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    # HIP events on the stream the kernel is launched on (= torch's current stream, passed to the C ABI)
+    # HIP events on the stream the kernel is launched on: torch's current stream, whose handle is what
+    # solve_torch passes to mpc_solve_batch_device (a NULL handle is HIP's null stream = torch's default)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -75,12 +75,64 @@ enum : int { MC_SP = 0, MC_CP, MC_SE, MC_CE, MC_FP, MC_G1, MC_H3, MC_FPP, MC_C =
 MPC_HD int64_t workspace_doubles_per_instance(int N) { return (int64_t)(N - 1) * STAGE_SZ; }
 
 /* Workspace accessor for struct-of-arrays storage: element e of instance i is
- * at base[e * stride + i]. */
+ * at base[e * stride + i].  On the device the pointer is typed into the GLOBAL
+ * address space so that every access is a global_load/global_store (a generic
+ * pointer would make them flat_* instructions, which cannot overlap). */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double gdouble;
+#else
+typedef double gdouble;
+#endif
 struct SoaWorkspace {
-  double *base;
+  gdouble *base;
   int64_t stride;
-  MPC_HD double &operator()(int k, int f) const { return base[(int64_t)(k * STAGE_SZ + f) * stride]; }
+  MPC_HD gdouble &operator()(int k, int f) const { return base[(int64_t)(k * STAGE_SZ + f) * stride]; }
 };
+
+/* ---- light-weight math (same code on device and in the test-only host build) ---- */
+/* reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the barrier terms need dozens of 1/slack
+ * per stage and a full IEEE division costs ~3x as many instructions */
+MPC_HD double frcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+/* x^p for the line-search switching heuristics only (thresholds, not results): single precision */
+MPC_HD double hpow(double x, double p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float xf = (float)fmin(x, 1e16);
+  return (double)__builtin_exp2f((float)p * __builtin_log2f(xf));
+#else
+  return pow(x, p);
+#endif
+}
+/* sin and cos together for the moderate angles of this model (psi, epsi): Cody-Waite reduction by
+ * pi/2 (two FMAs, exact enough for |x| < 1e5) and the classic minimax kernels on [-pi/4, pi/4]
+ * (coefficients as published in fdlibm's k_sin.c / k_cos.c); larger arguments take libm's path. */
+MPC_HD void fsincos(double x, double *sn, double *cs) {
+  if (!(fabs(x) < 1.0e5)) { ::sincos(x, sn, cs); return; }
+  const double kf = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632679489655800e+00, x);
+  r = fma(-kf, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s0 = fma(r * z, ps, r);
+  const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)kf & 3;
+  const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
 
 /* IPOPT default constants (Waechter & Biegler 2006; IPOPT 3.12 option defaults) */
 struct IpmConst {
@@ -116,6 +168,12 @@ struct Eval {
   bool ok;
 };
 
+#if defined(__HIPCC__) || defined(__clang__)
+#define MPC_UNROLL _Pragma("unroll")
+#else
+#define MPC_UNROLL _Pragma("GCC unroll 8")
+#endif
+
 template <class WS>
 struct Solver {
   const MpcParams &P;
@@ -133,9 +191,8 @@ struct Solver {
   Eval E;
   /* direction summary */
   double amax, az, dphi, dxinf, xinf;
-  /* filter */
-  enum { FMAX = 8 };
-  double fth[FMAX], fph[FMAX];
+  /* filter: four entries in registers (it is emptied at every barrier update) */
+  double fth0, fth1, fth2, fth3, fph0, fph1, fph2, fph3;
   int nf;
   int iters, n_reg;
 
@@ -156,17 +213,17 @@ struct Solver {
   /* model of stage k at (s,u): trig cache + F(s,u), MPC.cpp:142-152 */
   MPC_HD void model(const double *s, double delta, double a, double *m8, double *F) const {
     double sp, cp, se, ce;
-    ::sincos(s[2], &sp, &cp);
-    ::sincos(s[5], &se, &ce);
+    fsincos(s[2], &sp, &cp);
+    fsincos(s[5], &se, &ce);
     double f, fp, fpp, fppp;
     poly(s[0], f, fp, fpp, fppp);
-    const double q1 = 1.0 + fp * fp;
+    const double q1 = 1.0 + fp * fp, iq1 = frcp(q1);
     m8[MC_SP] = sp; m8[MC_CP] = cp; m8[MC_SE] = se; m8[MC_CE] = ce; m8[MC_FP] = fp;
-    m8[MC_G1] = fpp / q1;
-    m8[MC_H3] = (fppp * q1 - 2.0 * fp * fpp * fpp) / (q1 * q1);
+    m8[MC_G1] = fpp * iq1;
+    m8[MC_H3] = (fppp * q1 - 2.0 * fp * fpp * fpp) * (iq1 * iq1);
     m8[MC_FPP] = fpp;
     const double vdt = s[3] * dt;
-    const double psin = s[2] + delta * vdt / P.Lf;
+    const double psin = s[2] + delta * vdt * iLf;
     F[0] = s[0] + cp * vdt;
     F[1] = s[1] + sp * vdt;
     F[2] = psin;
@@ -174,18 +231,19 @@ struct Solver {
     F[4] = (f - s[1]) + se * vdt;
     F[5] = psin - atan(fp);
   }
+  double iLf;
 
   /* cost + barrier terms of one state s_k (k>=1): Hessian diagonal and gradient */
   MPC_HD void state_terms(double psi, double v, double c, double e, double zlp, double zup, double zlv,
                           double zuv, double &Hpp, double &Hvv, double &Hee, double &Hcc, double &gp,
                           double &gv, double &ge, double &gc) const {
-    const double slp = psi - yl, sup = yu - psi, slv = v - vl, suv = vu - v;
-    Hpp = zlp / slp + zup / sup;
-    Hvv = df * 2.0 * wv + zlv / slv + zuv / suv;
+    const double islp = frcp(psi - yl), isup = frcp(yu - psi), islv = frcp(v - vl), isuv = frcp(vu - v);
+    Hpp = zlp * islp + zup * isup;
+    Hvv = df * 2.0 * wv + zlv * islv + zuv * isuv;
     Hee = df * 2.0 * we;
     Hcc = df * 2.0 * wc;
-    gp = -mu / slp + mu / sup;
-    gv = df * 2.0 * wv * (v - vref) - mu / slv + mu / suv;
+    gp = mu * (isup - islp);
+    gv = df * 2.0 * wv * (v - vref) + mu * (isuv - islv);
     ge = df * 2.0 * we * e;
     gc = df * 2.0 * wc * c;
   }
@@ -198,7 +256,12 @@ struct Solver {
   MPC_HD bool backward(double dw) {
     const int I = it(cur), C = mc(cur);
     double Pm[6][6], p[6], Pcc, pc; /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1 */
-    for (int i = 0; i < 6; i++) { p[i] = 0; for (int j = 0; j < 6; j++) Pm[i][j] = 0; }
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) {
+      p[i] = 0;
+      MPC_UNROLL
+      for (int j = 0; j < 6; j++) Pm[i][j] = 0;
+    }
     {
       const int ks = M - 1;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
@@ -210,21 +273,27 @@ struct Solver {
     }
     for (int k = M - 1; k >= 0; --k) {
       /* ---- linearisation of stage k ---- */
-      double v, psi_k = 0, c_k = 0, e_k = 0;
+      double v, psi_k = 0, c_k = 0, e_k = 0, zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
       if (k == 0) { v = st[3]; }
-      else { psi_k = ws(k - 1, I + F_S + 2); v = ws(k - 1, I + F_S + 3); c_k = ws(k - 1, I + F_S + 4); e_k = ws(k - 1, I + F_S + 5); }
+      else {
+        psi_k = ws(k - 1, I + F_S + 2); v = ws(k - 1, I + F_S + 3); c_k = ws(k - 1, I + F_S + 4); e_k = ws(k - 1, I + F_S + 5);
+        zlp = ws(k - 1, I + F_ZL + 0); zup = ws(k - 1, I + F_ZU + 0); zlv = ws(k - 1, I + F_ZL + 1); zuv = ws(k - 1, I + F_ZU + 1);
+        delprev = ws(k - 1, I + F_U + 0);
+      }
       const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
       const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
       const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
       const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
       const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
+      const double zld = ws(k, I + F_ZL + 2), zud = ws(k, I + F_ZU + 2), zla = ws(k, I + F_ZL + 3), zua = ws(k, I + F_ZU + 3);
+      const double r0 = -ws(k, C + MC_C + 0), r1 = -ws(k, C + MC_C + 1), r2 = -ws(k, C + MC_C + 2);
+      const double r3 = -ws(k, C + MC_C + 3), rc = -ws(k, C + MC_C + 4), r4 = -ws(k, C + MC_C + 5);
       const double vdt = v * dt;
       const double Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
       const double Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
-      /* r = -c_{k+1}; t = p + P r (d component of r is zero) */
-      const double r0 = -ws(k, C + MC_C + 0), r1 = -ws(k, C + MC_C + 1), r2 = -ws(k, C + MC_C + 2);
-      const double r3 = -ws(k, C + MC_C + 3), rc = -ws(k, C + MC_C + 4), r4 = -ws(k, C + MC_C + 5);
+      /* t = p + P r (the d component of r is zero) */
       double t[6];
+      MPC_UNROLL
       for (int i = 0; i < 6; i++)
         t[i] = p[i] + Pm[i][0] * r0 + Pm[i][1] * r1 + Pm[i][2] * r2 + Pm[i][3] * r3 + Pm[i][4] * r4;
       const double tc = pc + Pcc * rc;
@@ -242,53 +311,67 @@ struct Solver {
   } while (0)
       double qt[7];
       MPC_GT(t, tc, qt);
-      /* gradient of the stage's own control terms */
-      const double sld = delta - dl, sud = du - delta, sla = acc - al, sua = au - acc;
-      const double zld = ws(k, I + F_ZL + 2), zud = ws(k, I + F_ZU + 2), zla = ws(k, I + F_ZL + 3), zua = ws(k, I + F_ZU + 3);
+      /* the stage's own control terms */
+      const double isld = frcp(delta - dl), isud = frcp(du - delta), isla = frcp(acc - al), isua = frcp(au - acc);
       double ddl = 0, Hdd = 0;
-      if (k >= 1) { ddl = delta - ws(k - 1, I + F_U + 0); Hdd = df * 2.0 * wdd; }
-      const double gdel = df * 2.0 * wd * delta + Hdd * ddl - mu / sld + mu / sud;
-      const double gacc = -mu / sla + mu / sua;
+      if (k >= 1) { ddl = delta - delprev; Hdd = df * 2.0 * wdd; }
+      const double gdel = df * 2.0 * wd * delta + Hdd * ddl + mu * (isud - isld);
+      const double gacc = mu * (isua - isla);
       const double rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
+      const double Sgd = zld * isld + zud * isud, Sga = zla * isla + zua * isua;
+      double w5[6], w6[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { w5[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5]; w6[i] = dt * Pm[i][3]; }
       if (k == 0) {
         /* only the feed-forward of u_0 is needed (ds_0 = 0) */
-        double w5[6], o5[7], w6[6], o6[7];
-        for (int i = 0; i < 6; i++) { w5[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5]; w6[i] = dt * Pm[i][3]; }
+        double o5[7], o6[7];
         MPC_GT(w5, 0.0, o5);
         MPC_GT(w6, 0.0, o6);
-        const double Rdd = o5[5] + df * 2.0 * wd + zld / sld + zud / sud + dw;
+        const double Rdd = o5[5] + df * 2.0 * wd + Sgd + dw;
         const double Rda = o6[5];
-        const double Raa = o6[6] + zla / sla + zua / sua + dw;
+        const double Raa = o6[6] + Sga + dw;
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-        ws(0, F_G + 12) = -(Raa * rt_d - Rda * rt_a) / det;
-        ws(0, F_G + 13) = -(-Rda * rt_d + Rdd * rt_a) / det;
+        const double idet = frcp(det);
+        ws(0, F_G + 12) = -(Raa * rt_d - Rda * rt_a) * idet;
+        ws(0, F_G + 13) = -(-Rda * rt_d + Rdd * rt_a) * idet;
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
       double Mx[7][7];
       {
         double w[6], o[7];
+        MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = Pm[i][0] + Aex * Pm[i][4];
         MPC_GT(w, Pcc * Acx, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][0] = o[i];
+        MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = Pm[i][1];
         MPC_GT(w, -Pcc, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][1] = o[i];
+        MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = Axp * Pm[i][0] + Ayp * Pm[i][1] + Pm[i][2] + Pm[i][4];
         MPC_GT(w, 0.0, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][2] = o[i];
+        MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = Axv * Pm[i][0] + Ayv * Pm[i][1] + Apv * (Pm[i][2] + Pm[i][4]) + Pm[i][3];
         MPC_GT(w, Pcc * Acv, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][3] = o[i];
-        for (int i = 0; i < 6; i++) w[i] = 0.0;
-        MPC_GT(w, Pcc * Ace, o);
-        for (int i = 0; i < 7; i++) Mx[i][4] = o[i];
-        for (int i = 0; i < 6; i++) w[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5];
-        MPC_GT(w, 0.0, o);
+        {
+          /* input e only feeds cte+: column = G^T (0, Pcc*Ace) */
+          const double wcs = Pcc * Ace;
+          Mx[0][4] = Acx * wcs; Mx[1][4] = -wcs; Mx[2][4] = 0.0; Mx[3][4] = Acv * wcs; Mx[4][4] = Ace * wcs;
+          Mx[5][4] = 0.0; Mx[6][4] = 0.0;
+        }
+        MPC_GT(w5, 0.0, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][5] = o[i];
-        for (int i = 0; i < 6; i++) w[i] = dt * Pm[i][3];
-        MPC_GT(w, 0.0, o);
+        MPC_GT(w6, 0.0, o);
+        MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][6] = o[i];
       }
       /* ---- add the Lagrangian Hessian of stage k: -lam_{k+1}^T d2F ---- */
@@ -299,16 +382,19 @@ struct Solver {
       { const double h = -lc * dt * ce; Mx[3][4] += h; Mx[4][3] += h; }
       { const double h = -(lp + le) * dtLf; Mx[3][5] += h; Mx[5][3] += h; }
       /* control terms */
-      const double Rdd = Mx[5][5] + df * 2.0 * wd + Hdd + zld / sld + zud / sud + dw;
+      const double Rdd = Mx[5][5] + df * 2.0 * wd + Hdd + Sgd + dw;
       const double Rda = 0.5 * (Mx[5][6] + Mx[6][5]);
-      const double Raa = Mx[6][6] + zla / sla + zua / sua + dw;
+      const double Raa = Mx[6][6] + Sga + dw;
       const double det = Rdd * Raa - Rda * Rda;
       if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-      const double i11 = Raa / det, i12 = -Rda / det, i22 = Rdd / det;
+      const double idet = frcp(det);
+      const double i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
       /* S~ (2 x 6 over x,y,psi,v,e,d) */
       double Sd[6], Sa[6], Kd[6], Ka[6];
+      MPC_UNROLL
       for (int j = 0; j < 5; j++) { Sd[j] = Mx[5][j]; Sa[j] = Mx[6][j]; }
       Sd[5] = -Hdd; Sa[5] = 0.0;
+      MPC_UNROLL
       for (int j = 0; j < 6; j++) {
         Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
         Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
@@ -320,9 +406,10 @@ struct Solver {
       ws(k, F_G + 13) = kfa;
       /* ---- value function of stage k ---- */
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(psi_k, v, c_k, e_k, ws(k - 1, I + F_ZL + 0), ws(k - 1, I + F_ZU + 0), ws(k - 1, I + F_ZL + 1),
-                  ws(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      state_terms(psi_k, v, c_k, e_k, zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      MPC_UNROLL
       for (int i = 0; i < 6; i++) {
+        MPC_UNROLL
         for (int j = 0; j <= i; j++) {
           double q = (i < 5) ? 0.5 * (Mx[i][j] + Mx[j][i]) : ((j == 5) ? Hdd : 0.0);
           q += Sd[i] * Kd[j] + Sa[i] * Ka[j];
@@ -343,9 +430,10 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   MPC_HD void forward() {
     const int I = it(cur), C = mc(cur);
-    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0; /* ds_k: x,y,psi,v,c,e */
-    double ddprev = 0, delprev = 0;                         /* d(delta_{k-1}), delta_{k-1} */
-    amax = 1.0; az = 1.0; dphi = 0.0; dxinf = 0.0; xinf = 0.0;
+    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
+    double ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
+    double rmax = 0.0, rzmax = 0.0;                 /* largest step ratios: alpha = min(1, tau / ratio) */
+    dphi = 0.0; dxinf = 0.0; xinf = 0.0;
     for (int k = 0; k < M; ++k) {
       const double v = (k == 0) ? st[3] : ws(k - 1, I + F_S + 3);
       const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
@@ -368,31 +456,33 @@ struct Solver {
       ws(k, F_D + 0) = n0; ws(k, F_D + 1) = n1; ws(k, F_D + 2) = n2; ws(k, F_D + 3) = n3;
       ws(k, F_D + 4) = n4; ws(k, F_D + 5) = n5; ws(k, F_D + 6) = dd; ws(k, F_D + 7) = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
-      const double xs[4] = {ws(k, I + F_S + 2), ws(k, I + F_S + 3), delta, acc};
+      const double psn = ws(k, I + F_S + 2), vn = ws(k, I + F_S + 3);
+      const double xs[4] = {psn, vn, delta, acc};
       const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
       const double dx[4] = {n2, n3, dd, da};
+      MPC_UNROLL
       for (int b = 0; b < 4; b++) {
-        const double sl = xs[b] - lo[b], su = hi[b] - xs[b];
+        const double isl = frcp(xs[b] - lo[b]), isu = frcp(hi[b] - xs[b]);
         const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
-        if (dx[b] < 0.0) amax = fmin(amax, -tau * sl / dx[b]);
-        if (dx[b] > 0.0) amax = fmin(amax, tau * su / dx[b]);
-        const double dzl = mu / sl - zl - zl / sl * dx[b];
-        const double dzu = mu / su - zu + zu / su * dx[b];
-        if (dzl < 0.0) az = fmin(az, -tau * zl / dzl);
-        if (dzu < 0.0) az = fmin(az, -tau * zu / dzu);
-        dphi += (-mu / sl + mu / su) * dx[b];
+        rmax = fmax(rmax, fmax(-dx[b] * isl, dx[b] * isu));
+        const double dzl = mu * isl - zl - zl * isl * dx[b];
+        const double dzu = mu * isu - zu + zu * isu * dx[b];
+        rzmax = fmax(rzmax, fmax(-dzl * frcp(zl), -dzu * frcp(zu)));
+        dphi += mu * (isu - isl) * dx[b];
       }
       /* objective part of the directional derivative */
-      const double cn = ws(k, I + F_S + 4), en = ws(k, I + F_S + 5), vn = xs[1];
+      const double cn = ws(k, I + F_S + 4), en = ws(k, I + F_S + 5);
       double g = 2.0 * wc * cn * n4 + 2.0 * we * en * n5 + 2.0 * wv * (vn - vref) * n3 + 2.0 * wd * delta * dd;
       if (k > 0) g += 2.0 * wdd * (delta - delprev) * (dd - ddprev);
       dphi += df * g;
       dxinf = fmax(dxinf, fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
                                fmax(fmax(fabs(n4), fabs(n5)), fmax(fabs(dd), fabs(da)))));
       xinf = fmax(xinf, fmax(fmax(fabs(ws(k, I + F_S + 0)), fabs(ws(k, I + F_S + 1))), fmax(fabs(vn), fabs(cn))));
-      d0 = n0; d1 = n1; d2 = n2; d3 = n3; d4 = n4; d5 = n5; ddprev = dd; delprev = delta;
+      d0 = n0; d1 = n1; d2 = n2; d3 = n3; d5 = n5; ddprev = dd; delprev = delta;
     }
-    (void)d4;
+    /* fraction to the boundary, W&B eq. (15): alpha = min(1, tau / max ratio) */
+    amax = (rmax > tau) ? tau / rmax : 1.0;
+    az = (rzmax > tau) ? tau / rzmax : 1.0;
   }
 
   /* ------------------------------------------------------------------ */
@@ -425,12 +515,14 @@ struct Solver {
       const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
       const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
       const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
+      const double dxk = ws(k - 1, F_D + 0), dyk = ws(k - 1, F_D + 1), dpk = ws(k - 1, F_D + 2), dvk = ws(k - 1, F_D + 3);
+      const double dck = ws(k - 1, F_D + 4), dek = ws(k - 1, F_D + 5), ddk = ws(k, F_D + 6);
+      const double lo0 = ws(k - 1, I + F_LAM + 0), lo1 = ws(k - 1, I + F_LAM + 1), lo2 = ws(k - 1, I + F_LAM + 2);
+      const double lo3 = ws(k - 1, I + F_LAM + 3), lo4 = ws(k - 1, I + F_LAM + 4), lo5 = ws(k - 1, I + F_LAM + 5);
       const double vdt = v * dt, Apv = delta * dtLf;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(psi, v, c, e, ws(k - 1, I + F_ZL + 0), ws(k - 1, I + F_ZU + 0), ws(k - 1, I + F_ZL + 1),
                   ws(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      const double dxk = ws(k - 1, F_D + 0), dyk = ws(k - 1, F_D + 1), dpk = ws(k - 1, F_D + 2), dvk = ws(k - 1, F_D + 3);
-      const double dck = ws(k - 1, F_D + 4), dek = ws(k - 1, F_D + 5), ddk = ws(k, F_D + 6);
       /* curvature of stage k */
       const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
       const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
@@ -443,9 +535,8 @@ struct Solver {
       const double n4 = -gc - (Hcc + dw) * dck;
       const double n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * dek - Hev * dvk;
       L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
-      ws(k - 1, F_D + 8) = L0 - ws(k - 1, I + F_LAM + 0); ws(k - 1, F_D + 9) = L1 - ws(k - 1, I + F_LAM + 1);
-      ws(k - 1, F_D + 10) = L2 - ws(k - 1, I + F_LAM + 2); ws(k - 1, F_D + 11) = L3 - ws(k - 1, I + F_LAM + 3);
-      ws(k - 1, F_D + 12) = L4 - ws(k - 1, I + F_LAM + 4); ws(k - 1, F_D + 13) = L5 - ws(k - 1, I + F_LAM + 5);
+      ws(k - 1, F_D + 8) = L0 - lo0; ws(k - 1, F_D + 9) = L1 - lo1; ws(k - 1, F_D + 10) = L2 - lo2;
+      ws(k - 1, F_D + 11) = L3 - lo3; ws(k - 1, F_D + 12) = L4 - lo4; ws(k - 1, F_D + 13) = L5 - lo5;
     }
   }
 
@@ -459,15 +550,23 @@ struct Solver {
     R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.ok = true;
     double s[6] = {st[0], st[1], st[2], st[3], st[4], st[5]};
     double lamk[6] = {0, 0, 0, 0, 0, 0};   /* lam_k of the trial point (k>=1) */
-    double zs[4] = {0, 0, 0, 0};           /* zl_psi, zu_psi, zl_v, zu_v of s_k */
+    double zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0; /* zl_psi, zu_psi, zl_v, zu_v of s_k */
     double rdel_prev = 0, delprev = 0;
+    const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
     for (int k = 0; k < M; ++k) {
-      const double delta = ws(k, I + F_U + 0) + alpha * ws(k, F_D + 6);
-      const double acc = ws(k, I + F_U + 1) + alpha * ws(k, F_D + 7);
-      double sn[6], ln[6];
+      const double delo = ws(k, I + F_U + 0), acco = ws(k, I + F_U + 1);
+      const double ddel = ws(k, F_D + 6), dacc = ws(k, F_D + 7);
+      const double delta = delo + alpha * ddel;
+      const double acc = acco + alpha * dacc;
+      double so[6], dso[6], sn[6], ln[6];
+      MPC_UNROLL
       for (int i = 0; i < 6; i++) {
-        sn[i] = ws(k, I + F_S + i) + alpha * ws(k, F_D + i);
+        so[i] = ws(k, I + F_S + i); dso[i] = ws(k, F_D + i);
+        sn[i] = so[i] + alpha * dso[i];
         ln[i] = ws(k, I + F_LAM + i) + alpha * ws(k, F_D + 8 + i);
+      }
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) {
         ws(k, J + F_S + i) = sn[i];
         ws(k, J + F_LAM + i) = ln[i];
         R.lsum += fabs(ln[i]);
@@ -475,29 +574,33 @@ struct Solver {
       ws(k, J + F_U + 0) = delta; ws(k, J + F_U + 1) = acc;
       double m8[8], F[6];
       model(s, delta, acc, m8, F);
+      MPC_UNROLL
       for (int i = 0; i < 8; i++) ws(k, CJ + i) = m8[i];
+      MPC_UNROLL
       for (int i = 0; i < 6; i++) {
         const double c = sn[i] - F[i];
         ws(k, CJ + MC_C + i) = c;
         R.theta += fabs(c); R.cinf = fmax(R.cinf, fabs(c));
       }
       /* duals of psi_{k+1}, v_{k+1}, delta_k, a_k */
-      const double xo[4] = {ws(k, I + F_S + 2), ws(k, I + F_S + 3), ws(k, I + F_U + 0), ws(k, I + F_U + 1)};
+      const double xo[4] = {so[2], so[3], delo, acco};
       const double xn[4] = {sn[2], sn[3], delta, acc};
-      const double dxb[4] = {ws(k, F_D + 2), ws(k, F_D + 3), ws(k, F_D + 6), ws(k, F_D + 7)};
+      const double dxb[4] = {dso[2], dso[3], ddel, dacc};
       const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
       double zln[4], zun[4], prod = 1.0;
+      MPC_UNROLL
       for (int b = 0; b < 4; b++) {
-        const double slo = xo[b] - lo[b], suo = hi[b] - xo[b];
+        const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
         const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
-        const double dzl = mu / slo - zl - zl / slo * dxb[b];
-        const double dzu = mu / suo - zu + zu / suo * dxb[b];
+        const double dzl = mu * islo - zl - zl * islo * dxb[b];
+        const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
         const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
         if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
+        const double isl = frcp(sl), isu = frcp(su);
         double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
         /* kappa_sigma safeguard, W&B eq. (16) */
-        a = fmax(fmin(a, IpmConst::kappa_sigma * mu / sl), mu / (IpmConst::kappa_sigma * sl));
-        c = fmax(fmin(c, IpmConst::kappa_sigma * mu / su), mu / (IpmConst::kappa_sigma * su));
+        a = fmax(fmin(a, ksm * isl), ksi * isl);
+        c = fmax(fmin(c, ksm * isu), ksi * isu);
         zln[b] = a; zun[b] = c;
         ws(k, J + F_ZL + b) = a; ws(k, J + F_ZU + b) = c;
         R.zsum += a + c;
@@ -517,10 +620,10 @@ struct Solver {
       if (k > 0) {
         const double r0 = lamk[0] - (ln[0] + m8[MC_FP] * ln[4] - m8[MC_G1] * ln[5]);
         const double r1 = lamk[1] - (ln[1] - ln[4]);
-        const double r2 = lamk[2] - (-vdt * m8[MC_SP] * ln[0] + vdt * m8[MC_CP] * ln[1] + l25) - zs[0] + zs[1];
+        const double r2 = lamk[2] - (-vdt * m8[MC_SP] * ln[0] + vdt * m8[MC_CP] * ln[1] + l25) - zs0 + zs1;
         const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] -
                           (dt * m8[MC_CP] * ln[0] + dt * m8[MC_SP] * ln[1] + Apv * l25 + ln[3] + dt * m8[MC_SE] * ln[4]) -
-                          zs[2] + zs[3];
+                          zs2 + zs3;
         const double r4 = df * 2.0 * wc * s[4] + lamk[4];
         const double r5 = df * 2.0 * we * s[5] + lamk[5] - vdt * m8[MC_CE] * ln[4];
         R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
@@ -531,15 +634,16 @@ struct Solver {
       const double ra = -dt * ln[3] - zln[3] + zun[3];
       R.dinf = fmax(R.dinf, fabs(ra));
       /* carry to the next stage */
+      MPC_UNROLL
       for (int i = 0; i < 6; i++) { s[i] = sn[i]; lamk[i] = ln[i]; }
-      zs[0] = zln[0]; zs[1] = zun[0]; zs[2] = zln[1]; zs[3] = zun[1];
+      zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
       delprev = delta;
     }
     /* last delta row has no successor; terminal state rows */
     R.dinf = fmax(R.dinf, fabs(rdel_prev));
     {
-      const double r2 = lamk[2] - zs[0] + zs[1];
-      const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] - zs[2] + zs[3];
+      const double r2 = lamk[2] - zs0 + zs1;
+      const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] - zs2 + zs3;
       const double r4 = df * 2.0 * wc * s[4] + lamk[4];
       const double r5 = df * 2.0 * we * s[5] + lamk[5];
       R.dinf = fmax(R.dinf, fmax(fmax(fabs(lamk[0]), fabs(lamk[1])), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
@@ -557,28 +661,42 @@ struct Solver {
   }
 
   MPC_HD bool filter_rejects(double th, double ph) const {
-    for (int i = 0; i < nf; i++)
-      if (th >= fth[i] && ph >= fph[i]) return true;
-    return false;
+    bool r = false;
+    r |= (nf > 0) && th >= fth0 && ph >= fph0;
+    r |= (nf > 1) && th >= fth1 && ph >= fph1;
+    r |= (nf > 2) && th >= fth2 && ph >= fph2;
+    r |= (nf > 3) && th >= fth3 && ph >= fph3;
+    return r;
   }
   MPC_HD void filter_add(double th, double ph) {
-    if (nf < FMAX) { fth[nf] = th; fph[nf] = ph; nf++; return; }
-    /* full: overwrite the entry with the largest theta (the least restrictive one) */
-    int w = 0;
-    for (int i = 1; i < FMAX; i++) if (fth[i] > fth[w]) w = i;
-    fth[w] = th; fph[w] = ph;
+    int slot = nf;
+    if (nf >= 4) {
+      /* full: overwrite the entry with the largest theta (the least restrictive one) */
+      slot = 0;
+      double worst = fth0;
+      if (fth1 > worst) { worst = fth1; slot = 1; }
+      if (fth2 > worst) { worst = fth2; slot = 2; }
+      if (fth3 > worst) { worst = fth3; slot = 3; }
+    } else nf++;
+    if (slot == 0) { fth0 = th; fph0 = ph; }
+    else if (slot == 1) { fth1 = th; fph1 = ph; }
+    else if (slot == 2) { fth2 = th; fph2 = ph; }
+    else { fth3 = th; fph3 = ph; }
   }
 
   /* ------------------------------------------------------------------ */
   /* set-up: instance constants, start point (MPC.cpp:204-257)           */
   /* ------------------------------------------------------------------ */
   MPC_HD int setup(const double *state6, const double *coef5, double yaw_lo, double yaw_hi, const double *w12) {
+    MPC_UNROLL
     for (int i = 0; i < 6; i++) st[i] = state6[i];
+    MPC_UNROLL
     for (int i = 0; i < MPC_NCOEF; i++) coef[i] = coef5[i];
     yl = yaw_lo; yu = yaw_hi;
-    M = P.N - 1; dt = P.dt; dtLf = P.dt / P.Lf;
+    M = P.N - 1; dt = P.dt; iLf = 1.0 / P.Lf; dtLf = P.dt / P.Lf;
     vl = -P.max_speed; vu = P.max_speed; dl = -P.max_steering; du = P.max_steering;
     al = P.max_deceleration; au = P.max_acceleration;
+    fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = 0.0;
     /* Branch outcomes at the start point xi = (state at index 0, zeros elsewhere):
      * for i >= 1 every variable is 0, so (MPC.cpp:72-112)
      *   |cte_i| < ctePanic  -> w[0] unless ctePanic <= 0
@@ -609,10 +727,13 @@ struct Solver {
       psi0 = fmin(fmax(psi0, yl + pl), yu - pu);
     }
     for (int k = 0; k < M; ++k) {
+      MPC_UNROLL
       for (int i = 0; i < 6; i++) { ws(k, IT0 + F_S + i) = 0.0; ws(k, IT0 + F_LAM + i) = 0.0; }
       ws(k, IT0 + F_S + 2) = psi0;
       ws(k, IT0 + F_U + 0) = 0.0; ws(k, IT0 + F_U + 1) = 0.0;
+      MPC_UNROLL
       for (int b = 0; b < 4; b++) { ws(k, IT0 + F_ZL + b) = 1.0; ws(k, IT0 + F_ZU + b) = 1.0; }
+      MPC_UNROLL
       for (int i = 0; i < D_SZ; i++) ws(k, F_D + i) = 0.0;
     }
     /* the fixed initial state must satisfy its own bounds (MPC.cpp:229-239 vs :269-281) */
@@ -656,10 +777,11 @@ struct Solver {
       costate(dw);
       /* filter line search, W&B algorithm A */
       const double theta_k = E.theta, phi_k = df * E.f - mu * E.L;
+      const double pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
+      const double pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
       double amin;
       if (dphi < 0.0) {
-        double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pow(theta_k, IpmConst::s_theta) / pow(-dphi, IpmConst::s_phi)
-                                           : IpmConst::gamma_theta;
+        const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
         amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
       } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
       const bool tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
@@ -673,7 +795,7 @@ struct Solver {
           const double phi_t = df * T.f - mu * T.L;
           const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
           if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
-            const bool sw = dphi < 0.0 && alpha * pow(-dphi, IpmConst::s_phi) > IpmConst::delta_sw * pow(theta_k, IpmConst::s_theta);
+            const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
             const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
             if (theta_k <= theta_min && sw) {
               if (armijo) accepted = true;
@@ -699,6 +821,7 @@ struct Solver {
   template <class OutF, class TrajF>
   MPC_HD void unpack(OutF out, TrajF traj, bool want_traj) const {
     const int I = it(cur);
+    MPC_UNROLL
     for (int i = 0; i < 6; i++) out(i) = ws(0, I + F_S + i);
     out(6) = ws(0, I + F_U + 0);
     out(7) = ws(0, I + F_U + 1);
@@ -711,8 +834,8 @@ struct Solver {
   }
 };
 
-/* One instance, end to end.  Loaders are functors so that the same code serves
- * the device kernel (struct-of-arrays HBM pointers) and the test-only host twin. */
+/* One instance, end to end (used by the test-only host build; the device kernel
+ * drives Solver directly so that outputs go straight to their HBM arrays). */
 template <class WS>
 MPC_HD int solve_instance(const MpcParams &P, WS ws, const double *state6, const double *coef5, double yaw_lo,
                           double yaw_hi, const double *w12, double *out9, double *traj2N, int *iters_out) {

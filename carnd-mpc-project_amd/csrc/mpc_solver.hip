@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 #pragma unroll
     for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
   }
-  mpc::SoaWorkspace ws{wsbase + i, ws_stride};
+  mpc::SoaWorkspace ws{(mpc::gdouble *)(wsbase + i), ws_stride};
   mpc::Solver<mpc::SoaWorkspace> S(P, ws);
   int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
@@ -169,7 +169,7 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
   h->last_B = B; h->last_status = status; h->last_iters = iters ? iters : h->d_iters; h->timed = false;
   if (B == 0) return MPC_OK;
-  hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+  hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
   hipLaunchKernelGGL(mpc_solve_kernel, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs, yaw_lo,
@@ -207,7 +207,7 @@ extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const d
   MPC_HIP_CHECK(hipMemcpyAsync(d_yhi, yaw_hi, sizeof(double) * B, hipMemcpyHostToDevice, s));
   if (weights) for (int q = 0; q < MPC_NW; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_w + q * S, weights + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
   int rc = mpc_solve_batch_device(h, B, S, d_state, d_coef, d_ylo, d_yhi, weights ? d_w : nullptr, d_o,
-                                  traj ? d_t : nullptr, h->d_status, h->d_iters, nullptr);
+                                  traj ? d_t : nullptr, h->d_status, h->d_iters, (void *)s);
   if (rc != MPC_OK) return rc;
   for (int q = 0; q < 9; q++) MPC_HIP_CHECK(hipMemcpyAsync(out + q * ld, d_o + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));
   if (traj) for (int q = 0; q < 2 * N; q++) MPC_HIP_CHECK(hipMemcpyAsync(traj + q * ld, d_t + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));

@@ -137,9 +137,9 @@ int mpc_abi_version(void);
  *   traj   [2N][ld]  x[0..N) then y[0..N) of the solution, or NULL (MPC.cpp:306-311)
  *   status [ld]      per-instance MPC_STATUS_*
  *   iters  [ld]      per-instance iteration count, or NULL
- * stream: a hipStream_t (as void*), NULL = the handle's own stream.  The call
- * is asynchronous with respect to the host; use mpc_synchronize() or the
- * caller's stream to wait.
+ * stream: the hipStream_t (as void*) to launch on; NULL is HIP's default (null)
+ * stream.  The call is asynchronous with respect to the host: order later work
+ * on the same stream, or synchronise that stream / the device, before reading.
  */
 int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *state,
                            const double *coeffs, const double *yaw_lo, const double *yaw_hi,

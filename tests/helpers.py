@@ -57,13 +57,13 @@ def oracle_solve_batch(cfg, batch, idx, opt=None, weights=None):
     return {"out": out, "traj": traj, "status": status, "iters": iters}
 
 
-def assert_parity(got_out, ref_out, got_traj=None, ref_traj=None, what=""):
+def assert_parity(got_out, ref_out, got_traj=None, ref_traj=None, what="", tol_accel=TOL_ACCEL):
     d_state = np.max(np.abs(got_out[:6] - ref_out[:6]))
     d_steer = np.max(np.abs(got_out[6] - ref_out[6]))
     d_acc = np.max(np.abs(got_out[7] - ref_out[7]))
     d_cost = np.max(np.abs(got_out[8] - ref_out[8]) / np.maximum(1.0, np.abs(ref_out[8])))
     assert d_steer <= TOL_STEER, "%s max |d steer| = %g rad" % (what, d_steer)
-    assert d_acc <= TOL_ACCEL, "%s max |d accel| = %g" % (what, d_acc)
+    assert d_acc <= tol_accel, "%s max |d accel| = %g" % (what, d_acc)
     assert d_state <= TOL_TRAJ, "%s max |d step-1 state| = %g" % (what, d_state)
     assert d_cost <= TOL_COST_REL, "%s max rel |d cost| = %g" % (what, d_cost)
     if got_traj is not None and ref_traj is not None:

@@ -92,8 +92,18 @@ def test_long_horizon_matches_oracle(pkg, golden_dir, waypoints, torch_dev):
     r = gpu_solve(pkg, params, b, torch_dev)
     assert (r["status"] == 0).all()
     idx = range(0, B, 4)
-    ref = oracle_solve_batch(O.load_config("config-stable.json", N=25, dt=0.05), b, idx)
-    assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25")
+    cfg = O.load_config("config-stable.json", N=25, dt=0.05)
+    ref = oracle_solve_batch(cfg, b, idx)
+    # At IPOPT's default tol = 1e-8 an INTERIOR a0 is only weakly determined (the frozen objective has no
+    # a^2 term, its curvature comes through v alone): two correct solvers stop up to ~1e-4 apart in a0 while
+    # agreeing in cost to 1e-9 and in delta0 to 1e-8.  So at the default tolerance a0 gets 1e-4 here ...
+    assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25", tol_accel=1e-4)
+    # ... and with both solvers tightened to 1e-10 they meet in the same point to the stated 1e-6.
+    tight = params.copy(); tight.tol = 1e-10
+    rt = gpu_solve(pkg, tight, b, torch_dev)
+    reft = oracle_solve_batch(cfg, b, idx, opt=O.default_options(tol=1e-10))
+    assert (rt["status"] == 0).all() and (reft["status"] == 0).all()
+    assert_parity(rt["out"][:, ::4], reft["out"], rt["traj"][:, ::4], reft["traj"], "N=25 tol 1e-10")
 
 
 def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev):
