@@ -88,6 +88,15 @@ struct SoaWorkspace {
   int64_t stride;
   MPC_HD gdouble &operator()(int k, int f) const { return base[(int64_t)(k * STAGE_SZ + f) * stride]; }
 };
+/* Device layout: the workspace is tiled per wavefront, [wave][stage*field][64 lanes].  One wave's
+ * whole working set is then ONE contiguous block (N=10: 900 x 512 B = 450 KB): every access of a
+ * wave is a single 512-byte line and consecutive fields are adjacent in memory, which keeps DRAM
+ * pages and TLB entries local to the wave instead of striding the batch (a [field][B] layout puts
+ * two fields of one wave 8*B bytes apart). */
+struct TiledWorkspace {
+  gdouble *base;   /* already offset to this lane: wave_block + lane */
+  MPC_HD gdouble &operator()(int k, int f) const { return base[(k * STAGE_SZ + f) * 64]; }
+};
 
 /* ---- light-weight math (same code on device and in the test-only host build) ---- */
 /* reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the barrier terms need dozens of 1/slack
@@ -195,6 +204,9 @@ struct Solver {
   double fth0, fth1, fth2, fth3, fph0, fph1, fph2, fph3;
   int nf;
   int iters, n_reg;
+  /* true only while the least-squares multiplier start is being computed: the sweeps then solve
+   * [I J^T; J 0][w; lam] = -[grad f; 0] (identity Hessian, no barrier, zero constraint rhs) */
+  bool lsm;
 
   MPC_HD Solver(const MpcParams &p, WS w) : P(p), ws(w) {}
 
@@ -238,12 +250,13 @@ struct Solver {
                           double zuv, double &Hpp, double &Hvv, double &Hee, double &Hcc, double &gp,
                           double &gv, double &ge, double &gc) const {
     const double islp = frcp(psi - yl), isup = frcp(yu - psi), islv = frcp(v - vl), isuv = frcp(vu - v);
-    Hpp = zlp * islp + zup * isup;
-    Hvv = df * 2.0 * wv + zlv * islv + zuv * isuv;
-    Hee = df * 2.0 * we;
-    Hcc = df * 2.0 * wc;
-    gp = mu * (isup - islp);
-    gv = df * 2.0 * wv * (v - vref) + mu * (isuv - islv);
+    const double mub = lsm ? 0.0 : mu;
+    Hpp = lsm ? 1.0 : zlp * islp + zup * isup;
+    Hvv = lsm ? 1.0 : df * 2.0 * wv + zlv * islv + zuv * isuv;
+    Hee = lsm ? 1.0 : df * 2.0 * we;
+    Hcc = lsm ? 1.0 : df * 2.0 * wc;
+    gp = mub * (isup - islp);
+    gv = df * 2.0 * wv * (v - vref) + mub * (isuv - islv);
     ge = df * 2.0 * we * e;
     gc = df * 2.0 * wc * c;
   }
@@ -268,9 +281,12 @@ struct Solver {
       state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
                   ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
                   Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      Pm[0][0] = dw; Pm[1][1] = dw; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
+      const double hxy = (lsm ? 1.0 : 0.0) + dw;   /* x and y carry no cost: only the LS identity / regularisation */
+      Pm[0][0] = hxy; Pm[1][1] = hxy; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
       Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
     }
+    const double rsc = lsm ? 0.0 : -1.0;             /* constraint right-hand side: -c, or 0 for the LS system */
+    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     for (int k = M - 1; k >= 0; --k) {
       /* ---- linearisation of stage k ---- */
       double v, psi_k = 0, c_k = 0, e_k = 0, zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
@@ -286,8 +302,8 @@ struct Solver {
       const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
       const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
       const double zld = ws(k, I + F_ZL + 2), zud = ws(k, I + F_ZU + 2), zla = ws(k, I + F_ZL + 3), zua = ws(k, I + F_ZU + 3);
-      const double r0 = -ws(k, C + MC_C + 0), r1 = -ws(k, C + MC_C + 1), r2 = -ws(k, C + MC_C + 2);
-      const double r3 = -ws(k, C + MC_C + 3), rc = -ws(k, C + MC_C + 4), r4 = -ws(k, C + MC_C + 5);
+      const double r0 = rsc * ws(k, C + MC_C + 0), r1 = rsc * ws(k, C + MC_C + 1), r2 = rsc * ws(k, C + MC_C + 2);
+      const double r3 = rsc * ws(k, C + MC_C + 3), rc = rsc * ws(k, C + MC_C + 4), r4 = rsc * ws(k, C + MC_C + 5);
       const double vdt = v * dt;
       const double Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
       const double Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
@@ -314,11 +330,13 @@ struct Solver {
       /* the stage's own control terms */
       const double isld = frcp(delta - dl), isud = frcp(du - delta), isla = frcp(acc - al), isua = frcp(au - acc);
       double ddl = 0, Hdd = 0;
-      if (k >= 1) { ddl = delta - delprev; Hdd = df * 2.0 * wdd; }
-      const double gdel = df * 2.0 * wd * delta + Hdd * ddl + mu * (isud - isld);
-      const double gacc = mu * (isua - isla);
+      if (k >= 1 && !lsm) { ddl = delta - delprev; Hdd = df * 2.0 * wdd; }   /* LS start: all delta are 0 */
+      const double mub = lsm ? 0.0 : mu;
+      const double gdel = df * 2.0 * wd * delta + Hdd * ddl + mub * (isud - isld);
+      const double gacc = mub * (isua - isla);
       const double rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
-      const double Sgd = zld * isld + zud * isud, Sga = zla * isla + zua * isua;
+      /* control Hessian diagonal: cost + barrier, or the identity of the LS system */
+      const double Sgd = lsm ? 1.0 : df * 2.0 * wd + zld * isld + zud * isud, Sga = lsm ? 1.0 : zla * isla + zua * isua;
       double w5[6], w6[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++) { w5[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5]; w6[i] = dt * Pm[i][3]; }
@@ -327,7 +345,7 @@ struct Solver {
         double o5[7], o6[7];
         MPC_GT(w5, 0.0, o5);
         MPC_GT(w6, 0.0, o6);
-        const double Rdd = o5[5] + df * 2.0 * wd + Sgd + dw;
+        const double Rdd = o5[5] + Sgd + dw;
         const double Rda = o6[5];
         const double Raa = o6[6] + Sga + dw;
         const double det = Rdd * Raa - Rda * Rda;
@@ -382,7 +400,7 @@ struct Solver {
       { const double h = -lc * dt * ce; Mx[3][4] += h; Mx[4][3] += h; }
       { const double h = -(lp + le) * dtLf; Mx[3][5] += h; Mx[5][3] += h; }
       /* control terms */
-      const double Rdd = Mx[5][5] + df * 2.0 * wd + Hdd + Sgd + dw;
+      const double Rdd = Mx[5][5] + Hdd + Sgd + dw;
       const double Rda = 0.5 * (Mx[5][6] + Mx[6][5]);
       const double Raa = Mx[6][6] + Sga + dw;
       const double det = Rdd * Raa - Rda * Rda;
@@ -417,7 +435,7 @@ struct Solver {
         }
         p[i] = ((i < 5) ? qt[i] : -Hdd * ddl) + Sd[i] * kfd + Sa[i] * kfa;
       }
-      Pm[0][0] += dw; Pm[1][1] += dw; Pm[2][2] += Hpp + dw; Pm[3][3] += Hvv + dw; Pm[4][4] += Hee + dw;
+      Pm[0][0] += hxy; Pm[1][1] += hxy; Pm[2][2] += Hpp + dw; Pm[3][3] += Hvv + dw; Pm[4][4] += Hee + dw;
       p[2] += gp; p[3] += gv; p[4] += ge;
       Pcc = Hcc + dw; pc = gc;
     }
@@ -433,6 +451,7 @@ struct Solver {
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
     double ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
     double rmax = 0.0, rzmax = 0.0;                 /* largest step ratios: alpha = min(1, tau / ratio) */
+    const double rsc = lsm ? 0.0 : 1.0;
     dphi = 0.0; dxinf = 0.0; xinf = 0.0;
     for (int k = 0; k < M; ++k) {
       const double v = (k == 0) ? st[3] : ws(k - 1, I + F_S + 3);
@@ -447,12 +466,12 @@ struct Solver {
       const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
       const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1);
       const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
-      const double n0 = d0 - vdt * sp * d2 + dt * cp * d3 - ws(k, C + MC_C + 0);
-      const double n1 = d1 + vdt * cp * d2 + dt * sp * d3 - ws(k, C + MC_C + 1);
-      const double n2 = d2 + Apv * d3 + Bp * dd - ws(k, C + MC_C + 2);
-      const double n3 = d3 + dt * da - ws(k, C + MC_C + 3);
-      const double n4 = fp * d0 - d1 + dt * se * d3 + vdt * ce * d5 - ws(k, C + MC_C + 4);
-      const double n5 = -g1 * d0 + d2 + Apv * d3 + Bp * dd - ws(k, C + MC_C + 5);
+      const double n0 = d0 - vdt * sp * d2 + dt * cp * d3 - rsc * ws(k, C + MC_C + 0);
+      const double n1 = d1 + vdt * cp * d2 + dt * sp * d3 - rsc * ws(k, C + MC_C + 1);
+      const double n2 = d2 + Apv * d3 + Bp * dd - rsc * ws(k, C + MC_C + 2);
+      const double n3 = d3 + dt * da - rsc * ws(k, C + MC_C + 3);
+      const double n4 = fp * d0 - d1 + dt * se * d3 + vdt * ce * d5 - rsc * ws(k, C + MC_C + 4);
+      const double n5 = -g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * ws(k, C + MC_C + 5);
       ws(k, F_D + 0) = n0; ws(k, F_D + 1) = n1; ws(k, F_D + 2) = n2; ws(k, F_D + 3) = n3;
       ws(k, F_D + 4) = n4; ws(k, F_D + 5) = n5; ws(k, F_D + 6) = dd; ws(k, F_D + 7) = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
@@ -498,8 +517,9 @@ struct Solver {
       state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
                   ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
                   Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      L0 = -(dw * ws(ks, F_D + 0));
-      L1 = -(dw * ws(ks, F_D + 1));
+      const double hxy = (lsm ? 1.0 : 0.0) + dw;
+      L0 = -(hxy * ws(ks, F_D + 0));
+      L1 = -(hxy * ws(ks, F_D + 1));
       L2 = -(gp + (Hpp + dw) * ws(ks, F_D + 2));
       L3 = -(gv + (Hvv + dw) * ws(ks, F_D + 3));
       L4 = -(gc + (Hcc + dw) * ws(ks, F_D + 4));
@@ -508,6 +528,7 @@ struct Solver {
       ws(ks, F_D + 10) = L2 - ws(ks, I + F_LAM + 2); ws(ks, F_D + 11) = L3 - ws(ks, I + F_LAM + 3);
       ws(ks, F_D + 12) = L4 - ws(ks, I + F_LAM + 4); ws(ks, F_D + 13) = L5 - ws(ks, I + F_LAM + 5);
     }
+    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     for (int k = M - 1; k >= 1; --k) {
       const double psi = ws(k - 1, I + F_S + 2), v = ws(k - 1, I + F_S + 3), c = ws(k - 1, I + F_S + 4), e = ws(k - 1, I + F_S + 5);
       const double delta = ws(k, I + F_U + 0);
@@ -527,8 +548,8 @@ struct Solver {
       const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
       const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
       const double L25 = L2 + L5;
-      const double n0 = L0 + fp * L4 - g1 * L5 - (Hxx + dw) * dxk;
-      const double n1 = L1 - L4 - dw * dyk;
+      const double n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * dxk;
+      const double n1 = L1 - L4 - hxy * dyk;
       const double n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * dpk - Hpv * dvk;
       const double n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * dpk -
                         (Hvv + dw) * dvk - Hev * dek - Hvd * ddk;
@@ -684,6 +705,21 @@ struct Solver {
     else { fth3 = th; fph3 = ph; }
   }
 
+  double psi_start;
+  /* the start point of MPC.cpp:207-210 (zeros), pushed into the interior, in iterate slot 0 */
+  MPC_HD void start_point() {
+    for (int k = 0; k < M; ++k) {
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { ws(k, IT0 + F_S + i) = 0.0; ws(k, IT0 + F_LAM + i) = 0.0; }
+      ws(k, IT0 + F_S + 2) = psi_start;
+      ws(k, IT0 + F_U + 0) = 0.0; ws(k, IT0 + F_U + 1) = 0.0;
+      MPC_UNROLL
+      for (int b = 0; b < 4; b++) { ws(k, IT0 + F_ZL + b) = 1.0; ws(k, IT0 + F_ZU + b) = 1.0; }
+      MPC_UNROLL
+      for (int i = 0; i < D_SZ; i++) ws(k, F_D + i) = 0.0;
+    }
+  }
+
   /* ------------------------------------------------------------------ */
   /* set-up: instance constants, start point (MPC.cpp:204-257)           */
   /* ------------------------------------------------------------------ */
@@ -726,16 +762,8 @@ struct Solver {
       const double pu = fmin(IpmConst::kappa1 * fmax(1.0, fabs(yu)), IpmConst::kappa2 * (yu - yl));
       psi0 = fmin(fmax(psi0, yl + pl), yu - pu);
     }
-    for (int k = 0; k < M; ++k) {
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) { ws(k, IT0 + F_S + i) = 0.0; ws(k, IT0 + F_LAM + i) = 0.0; }
-      ws(k, IT0 + F_S + 2) = psi0;
-      ws(k, IT0 + F_U + 0) = 0.0; ws(k, IT0 + F_U + 1) = 0.0;
-      MPC_UNROLL
-      for (int b = 0; b < 4; b++) { ws(k, IT0 + F_ZL + b) = 1.0; ws(k, IT0 + F_ZU + b) = 1.0; }
-      MPC_UNROLL
-      for (int i = 0; i < D_SZ; i++) ws(k, F_D + i) = 0.0;
-    }
+    psi_start = psi0;
+    start_point();
     /* the fixed initial state must satisfy its own bounds (MPC.cpp:229-239 vs :269-281) */
     if (!(st[2] >= yl && st[2] <= yu) || !(fabs(st[3]) <= P.max_speed) || !(yl < yu)) return MPC_STATUS_INFEASIBLE;
     return MPC_STATUS_SUCCESS;
@@ -745,10 +773,53 @@ struct Solver {
   /* the interior-point iteration                                         */
   /* ------------------------------------------------------------------ */
   MPC_HD int solve() {
-    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0;
+    int status = solve_from_start(true);
+    if (status == MPC_STATUS_LINESEARCH || status == MPC_STATUS_MAXITER) {
+      /* IPOPT would enter its feasibility-restoration phase here.  Stand-in (same as the oracle's):
+       * restart from the start point with zero equality multipliers. */
+      const int it1 = iters;
+      start_point();
+      status = solve_from_start(false);
+      iters += it1;
+    }
+    return status;
+  }
+
+  MPC_HD int solve_from_start(bool ls_start) {
+    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
     E = trial(0.0, 0.0);
     cur = 1;
     if (!E.ok) return MPC_STATUS_NUMERIC;
+    /* least-squares start for the equality multipliers (IPOPT default; W&B section 3.6): one extra
+     * Riccati pass with identity Hessian.  Estimates above constr_mult_init_max = 1000 are discarded. */
+    if (ls_start) {
+      lsm = true;
+      const bool okb = backward(0.0);
+      double lmax = 0.0;
+      if (okb) {
+        forward();
+        costate(0.0);
+        for (int k = 0; k < M; ++k) {
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) lmax = fmax(lmax, fabs(ws(k, F_D + 8 + i)));
+        }
+      }
+      lsm = false;
+      const bool use = okb && (lmax <= 1000.0);
+      for (int k = 0; k < M; ++k) {
+        MPC_UNROLL
+        for (int i = 0; i < 8; i++) ws(k, F_D + i) = 0.0;
+        if (!use) {
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) ws(k, F_D + 8 + i) = 0.0;
+        }
+      }
+      if (use) {
+        E = trial(1.0, 0.0);          /* lam <- lam_LS; primal point and bound duals unchanged */
+        cur = 1 - cur;
+        if (!E.ok) return MPC_STATUS_NUMERIC;
+      }
+    }
     const double theta_max = 1e4 * fmax(1.0, E.theta), theta_min = 1e-4 * fmax(1.0, E.theta);
     const double mu_floor = P.tol / 10.0;
     double dw_last = 0.0;
@@ -775,6 +846,10 @@ struct Solver {
       if (dw > 0.0) { dw_last = dw; n_reg++; }
       forward();
       costate(dw);
+#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+      printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e dw=%.1e amax=%.3g az=%.3g dphi=%.3e nf=%d\n", iter,
+             E.f, E.theta, E.dinf, E.cmin, E.cmax, mu, E0, dw, amax, az, dphi, nf);
+#endif
       /* filter line search, W&B algorithm A */
       const double theta_k = E.theta, phi_k = df * E.f - mu * E.L;
       const double pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */

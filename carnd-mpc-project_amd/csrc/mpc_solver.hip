@@ -56,8 +56,9 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 #pragma unroll
     for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
   }
-  mpc::SoaWorkspace ws{(mpc::gdouble *)(wsbase + i), ws_stride};
-  mpc::Solver<mpc::SoaWorkspace> S(P, ws);
+  /* per-wave tile of the workspace; ws_stride = doubles per wave tile */
+  mpc::TiledWorkspace ws{(mpc::gdouble *)(wsbase + (i >> 6) * ws_stride + (i & 63))};
+  mpc::Solver<mpc::TiledWorkspace> S(P, ws);
   int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
   else { S.cur = 0; S.E.f = 0.0; S.iters = 0; }
@@ -76,7 +77,8 @@ struct MpcHandle {
   MpcParams params;
   int device = 0;
   int64_t max_batch = 0;
-  int64_t ws_stride = 0;
+  int64_t ws_stride = 0;   /* doubles per wavefront tile of the workspace */
+  int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   double *ws = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -122,16 +124,17 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   MpcHandle *h = new MpcHandle();
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  h->ws_stride = (max_batch + 63) / 64 * 64;
-  const size_t ws_bytes = (size_t)mpc::workspace_doubles_per_instance(p->N) * (size_t)h->ws_stride * sizeof(double);
+  h->ws_stride = mpc::workspace_doubles_per_instance(p->N) * 64;       /* doubles per wavefront tile */
+  h->io_stride = (max_batch + 63) / 64 * 64;
+  const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
   if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
   if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
-  if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->ws_stride)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->ws_stride)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   *out = h;
   return MPC_OK;
 }
@@ -164,11 +167,12 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
                                       const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                                       const double *weights, double *out, double *traj, int32_t *status,
                                       int32_t *iters, void *stream_) {
-  if (!h || !state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
   if (B < 0 || ld < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
   h->last_B = B; h->last_status = status; h->last_iters = iters ? iters : h->d_iters; h->timed = false;
-  if (B == 0) return MPC_OK;
+  if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
+  if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
@@ -190,12 +194,13 @@ extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const d
                                     const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                                     const double *weights, double *out, double *traj, int32_t *status,
                                     int32_t *iters) {
-  if (!h || !state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
   if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
-  if (B == 0) return MPC_OK;
+  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   MPC_HIP_CHECK(hipSetDevice(h->device));
   const int N = h->params.N;
-  const int64_t S = h->ws_stride;
+  const int64_t S = h->io_stride;
   if (!h->d_in) MPC_HIP_CHECK(hipMalloc((void **)&h->d_in, sizeof(double) * 25 * S));
   if (!h->d_out) MPC_HIP_CHECK(hipMalloc((void **)&h->d_out, sizeof(double) * (9 + 2 * MPC_MAX_N) * S));
   double *d_state = h->d_in, *d_coef = d_state + 6 * S, *d_ylo = d_coef + 5 * S, *d_yhi = d_ylo + S, *d_w = d_yhi + S;
