@@ -63,8 +63,8 @@ namespace mpc {
 enum : int {
   F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
-  MC0 = 2 * IT_SZ, MC_SZ = 14, MC1 = MC0 + MC_SZ,                  /* double-buffered model cache */
-  F_D = MC1 + MC_SZ,                                               /* ds[6] du[2] dlam[6] */
+  MC0 = 2 * IT_SZ, MC_SZ = 14,                                     /* model cache (single slot) */
+  F_D = MC0 + MC_SZ,                                               /* ds[6] du[2] dlam[6] */
   D_SZ = 14,
   F_G = F_D + D_SZ,                                                /* K[2][6] kff[2] */
   G_SZ = 14,
@@ -211,7 +211,9 @@ struct Solver {
   MPC_HD Solver(const MpcParams &p, WS w) : P(p), ws(w) {}
 
   MPC_HD int it(int slot) const { return slot ? IT1 : IT0; }
-  MPC_HD int mc(int slot) const { return slot ? MC1 : MC0; }
+  /* the model cache needs no second slot: backward/forward/costate of an iteration have all run
+   * before the trial point overwrites it, and a rejected trial is simply overwritten by the next */
+  MPC_HD int mc(int) const { return MC0; }
 
   /* ---- road polynomial: RoadGeometry::centerY / orientation, utils.h:28-47 */
   MPC_HD void poly(double x, double &f, double &fp, double &fpp, double &fppp) const {
@@ -774,7 +776,7 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   MPC_HD int solve() {
     int status = solve_from_start(true);
-    if (status == MPC_STATUS_LINESEARCH || status == MPC_STATUS_MAXITER) {
+    if (status == MPC_STATUS_LINESEARCH) {
       /* IPOPT would enter its feasibility-restoration phase here.  Stand-in (same as the oracle's):
        * restart from the start point with zero equality multipliers. */
       const int it1 = iters;

@@ -980,7 +980,7 @@ int orc_mpc_solve(const OrcConfig *cfg, const OrcSolveOptions *opt_in, const dou
     free(x0); free(prev);
   } else {
     status = ipm_solve(&P, &opt, xi, x, NULL, &info);
-    if ((status == ORC_RESTORATION_FAILURE || status == ORC_MAXITER_EXCEEDED) && opt.lam_init_ls) {
+    if (status == ORC_RESTORATION_FAILURE && opt.lam_init_ls) {
       /* IPOPT would switch to its feasibility-restoration phase here, which this oracle does not
        * restate.  Stand-in: restart from the same start point with zero equality multipliers
        * (what IPOPT itself falls back to when the least-squares estimate is rejected). */

@@ -20,5 +20,9 @@ echo "== rocprofv3 pmc (separate passes)" | tee -a $OUT/${TAG}_progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_fetch.err; echo "pmc fetch exit=$?" | tee -a $OUT/${TAG}_progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_write.err; echo "pmc write exit=$?" | tee -a $OUT/${TAG}_progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/${TAG}_pmc_sq -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_sq.err; echo "pmc sq exit=$?" | tee -a $OUT/${TAG}_progress.log
-find $OUT -name "*.csv" | head -40
+echo "== FETCH/WRITE calibration at 8 B per lane" | tee -a $OUT/${TAG}_progress.log
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/calib_fetch $R/tools/calib_fetch.hip > $OUT/${TAG}_calib_build.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_calib_fetch -o pmc -- /tmp/calib_fetch > $OUT/${TAG}_calib.log 2>&1; echo "calib fetch exit=$?" | tee -a $OUT/${TAG}_progress.log
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_calib_write -o pmc -- /tmp/calib_fetch >> $OUT/${TAG}_calib.log 2>&1; echo "calib write exit=$?" | tee -a $OUT/${TAG}_progress.log
+find $OUT -name "*.csv" | grep ${TAG} | head -40
 echo done | tee -a $OUT/${TAG}_progress.log

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/gpu_round.sh (gpurun_out/<tag>_*) into profiles/<name>_*.
+   python tools/summarize_profiles.py <tag> <name>"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+shutil.copy(os.path.join(G, tag + "_prof", "trace_kernel_stats.csv"), os.path.join(P, name + "_kernel_stats.csv"))
+bench = json.load(open(os.path.join(G, tag + "_bench.json")))
+json.dump(bench, open(os.path.join(P, name + "_bench.json"), "w"), indent=1)
+
+
+def pmc(sub, kernel):
+    rows = list(csv.DictReader(open(os.path.join(G, tag + "_" + sub, "pmc_counter_collection.csv"))))
+    agg = collections.defaultdict(list)
+    meta = {}
+    for r in rows:
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}, meta
+
+
+out = {"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (separate passes)",
+       "kernel": "mpc_solve_kernel", "per": "launch (mean over the profiled launches)"}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    m, n, meta = pmc(sub, "mpc_solve_kernel")
+    out.update(m); out.setdefault("launches", {}).update(n); out["dispatch"] = meta
+# calibration of FETCH_SIZE / WRITE_SIZE on a known byte count with the same access width (tools/calib_fetch.hip)
+cal = {}
+for sub, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    f = os.path.join(G, tag + "_" + sub, "pmc_counter_collection.csv")
+    if os.path.exists(f):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "calib_copy8" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        if vals:
+            cal[ctr] = {"counter_kb_per_launch": sum(vals) / len(vals), "true_bytes_per_launch": (1 << 28) * 8,
+                        "bytes_per_counter_kb": (1 << 28) * 8 / (sum(vals) / len(vals))}
+out["calibration_8B_per_lane"] = cal
+fk = cal.get("FETCH_SIZE", {}).get("bytes_per_counter_kb", 1024.0)
+wk = cal.get("WRITE_SIZE", {}).get("bytes_per_counter_kb", 1024.0)
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    out["hbm_bytes_per_launch"] = out["FETCH_SIZE"] * fk + out["WRITE_SIZE"] * wk
+    out["hbm_bytes_note"] = "FETCH_SIZE and WRITE_SIZE are in KB; scaled by the calibration above when present (else x1024)"
+if "SQ_WAVE_CYCLES" in out:
+    out["wait_any_fraction_of_wave_cycles"] = out.get("SQ_WAIT_ANY", 0) / out["SQ_WAVE_CYCLES"]
+    out["active_inst_fraction_of_wave_cycles"] = out.get("SQ_ACTIVE_INST_ANY", 0) / out["SQ_WAVE_CYCLES"]
+json.dump(out, open(os.path.join(P, name + "_pmc_summary.json"), "w"), indent=1)
+cfg = bench["config"]
+json.dump({"batch": cfg["batch_per_gpu"], "config": "config-fast.json", "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"),
+           "from": name + "_pmc_summary.json"}, open(os.path.join(P, "round1_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
