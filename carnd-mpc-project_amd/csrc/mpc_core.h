@@ -21,18 +21,19 @@
  *     out of the 6x6 Riccati matrix as a scalar;
  *   - inertia correction = "every 2x2 R~_k positive definite", the Riccati
  *     equivalent of IPOPT's inertia test on the full KKT matrix.
- * Interior-point logic (monotone barrier, fraction-to-the-boundary, filter
- * line search, kappa_sigma dual reset, error scaling, gradient-based
- * objective scaling) follows Waechter & Biegler (2006) with IPOPT's default
- * constants so that the converged point is the one IPOPT's tolerance defines.
+ * Interior-point logic (least-squares multiplier start, monotone barrier,
+ * fraction-to-the-boundary, filter line search, kappa_sigma dual reset, error
+ * scaling, gradient-based objective scaling) follows Waechter & Biegler (2006)
+ * with IPOPT's default constants so that the converged point is the one
+ * IPOPT's tolerance defines.
  *
  * Mapping to the hardware: ONE INSTANCE PER LANE, 64 instances per wavefront.
  * Every instruction a wave issues is useful fp64 work for 64 independent
  * problems; there is no cross-lane traffic and no divergence except in
- * iteration counts.  All per-stage data live in a struct-of-arrays workspace
- * indexed [stage][field][instance] so that each load/store of a wave is one
- * fully coalesced 512-byte access.  (See DESIGN.md for why this beats one
- * instance per wavefront for 7x7 blocks.)
+ * iteration counts.  Per-stage data live in a per-wave tile of a workspace
+ * indexed [stage][field][lane] so that each load/store of a wave is one
+ * fully coalesced line.  (See DESIGN.md for why this beats one instance per
+ * wavefront for 6x6 blocks, and for the traffic accounting.)
  *
  * The same header compiles with g++ for tests/host_twin.cpp, a test-only CPU
  * build used to debug the algorithm in the GPU-less build container; the
@@ -48,55 +49,104 @@
 
 #if defined(__HIPCC__)
 #define MPC_HD __host__ __device__ __forceinline__
-#define MPC_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define MPC_HD inline
-#define MPC_HD_NOINLINE
+#endif
+#if defined(__HIPCC__) || defined(__clang__)
+#define MPC_UNROLL _Pragma("unroll")
+#else
+#define MPC_UNROLL _Pragma("GCC unroll 8")
 #endif
 
 namespace mpc {
 
-/* ---- workspace layout (doubles per stage) -------------------------------- */
-/* Stage k (0..N-2) owns: s_{k+1}, u_k, lam_{k+1}, the bound duals of
- * (psi_{k+1}, v_{k+1}, delta_k, a_k), the model cache of (s_k,u_k) incl. the
- * residual c_{k+1}, the Newton direction and the Riccati gains of u_k. */
+/* ---- workspace layout ------------------------------------------------------ */
+/* A "field" is one double per instance.  Stage k (0..N-2) owns:
+ *   two iterate slots: s_{k+1} (6), u_k (2), lam_{k+1} (6), bound duals of (psi_{k+1}, v_{k+1}, delta_k, a_k) (4+4)
+ *   the Newton direction  ds_{k+1} (6), du_k (2), dlam_{k+1} (6)   -- stored in fp32
+ *   the Riccati gains     K_k (2x6, fp32) and kff_k (2, fp64)      -- in LDS on the device when they fit
+ * Nothing else is kept: the stage model (sin/cos/atan, road polynomial, residual) is recomputed
+ * in every sweep, because the kernel is limited by workspace traffic, not by arithmetic.
+ * fp32 storage of direction and gains only makes the Newton step inexact at the 6e-8 level; all
+ * residuals, the iterate, the multipliers and the convergence test stay fp64. */
 enum : int {
   F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
-  MC0 = 2 * IT_SZ, MC_SZ = 14,                                     /* model cache (single slot) */
-  F_D = MC0 + MC_SZ,                                               /* ds[6] du[2] dlam[6] */
-  D_SZ = 14,
-  F_G = F_D + D_SZ,                                                /* K[2][6] kff[2] */
-  G_SZ = 14,
-  STAGE_SZ = F_G + G_SZ
+  F_D = 2 * IT_SZ, D_N = 14, D_FIELDS = 7,                         /* 14 floats = 7 fields */
+  F_GK = F_D + D_FIELDS, GK_N = 12, GK_FIELDS = 6,                 /* 12 floats = 6 fields (HBM fallback) */
+  F_GF = F_GK + GK_FIELDS, GF_N = 2,                               /* 2 doubles              (HBM fallback) */
+  STAGE_SZ_LDS = F_GK,                                             /* 51 fields/stage with gains in LDS */
+  STAGE_SZ_GLOBAL = F_GF + GF_N,                                   /* 59 fields/stage with gains in HBM */
+  STAGE_SZ_HOST = 2 * IT_SZ + D_N + GK_N + GF_N                    /* 72: test-only host build, all fp64 slots */
 };
-enum : int { MC_SP = 0, MC_CP, MC_SE, MC_CE, MC_FP, MC_G1, MC_H3, MC_FPP, MC_C = 8 };
+enum : int { D_S = 0, D_U = 6, D_LAM = 8 };                        /* direction entries */
 
-MPC_HD int64_t workspace_doubles_per_instance(int N) { return (int64_t)(N - 1) * STAGE_SZ; }
+MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
+  return (int64_t)(N - 1) * (gains_in_lds ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL);
+}
+/* LDS bytes per wavefront for the gains of an N-step horizon */
+MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N * 4 + GF_N * 8) * 64; }
 
-/* Workspace accessor for struct-of-arrays storage: element e of instance i is
- * at base[e * stride + i].  On the device the pointer is typed into the GLOBAL
- * address space so that every access is a global_load/global_store (a generic
- * pointer would make them flat_* instructions, which cannot overlap). */
+/* Plain storage for the test-only host build: one instance, fields contiguous.  Direction and
+ * gains are rounded through float on store so that the host build sees the device's numerics. */
+struct HostWorkspace {
+  double *base;
+  MPC_HD double &it(int k, int f) const { return base[k * STAGE_SZ_HOST + f]; }
+  MPC_HD double getD(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + j]; }
+  MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + j] = (double)(float)v; }
+  MPC_HD double getK(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + j]; }
+  MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + j] = (double)(float)v; }
+  MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + GK_N + j]; }
+  MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + GK_N + j] = v; }
+};
+
+#if defined(__HIPCC__)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double gdouble;
-#else
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) float lfloat;
+#else   /* host pass of hipcc: the kernel body is parsed but never run */
 typedef double gdouble;
+typedef float gfloat;
+typedef double ldouble;
+typedef float lfloat;
 #endif
-struct SoaWorkspace {
-  gdouble *base;
-  int64_t stride;
-  MPC_HD gdouble &operator()(int k, int f) const { return base[(int64_t)(k * STAGE_SZ + f) * stride]; }
-};
 /* Device layout: the workspace is tiled per wavefront, [wave][stage*field][64 lanes].  One wave's
- * whole working set is then ONE contiguous block (N=10: 900 x 512 B = 450 KB): every access of a
- * wave is a single 512-byte line and consecutive fields are adjacent in memory, which keeps DRAM
- * pages and TLB entries local to the wave instead of striding the batch (a [field][B] layout puts
- * two fields of one wave 8*B bytes apart). */
+ * whole working set is ONE contiguous block (N=10, gains in LDS: 51 x 9 x 512 B = 230 KB; all 1024
+ * waves of a 65536-instance launch: 235 MB, inside the 256 MB Infinity Cache): every access of a
+ * wave is a single 512-byte (fp64) or 256-byte (fp32) line and consecutive fields are adjacent in
+ * memory, which keeps DRAM pages and TLB entries local to the wave.  All pointers are typed into
+ * their address space so that accesses are global_* / ds_* instructions, never flat_*. */
+template <bool GAINS_IN_LDS>
 struct TiledWorkspace {
-  gdouble *base;   /* already offset to this lane: wave_block + lane */
-  MPC_HD gdouble &operator()(int k, int f) const { return base[(k * STAGE_SZ + f) * 64]; }
+  gdouble *tile;   /* this wave's tile */
+  lfloat *lk;      /* LDS: K, [stage][12][64] floats (when GAINS_IN_LDS) */
+  ldouble *lf;     /* LDS: kff, [stage][2][64] doubles */
+  int lane;
+  static constexpr int STAGE = GAINS_IN_LDS ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL;
+  MPC_HD gdouble &it(int k, int f) const { return tile[(k * STAGE + f) * 64 + lane]; }
+  MPC_HD gfloat *fptr(int k, int f0) const { return (gfloat *)(tile + (k * STAGE + f0) * 64); }
+  MPC_HD double getD(int k, int j) const { return (double)fptr(k, F_D)[j * 64 + lane]; }
+  MPC_HD void setD(int k, int j, double v) const { fptr(k, F_D)[j * 64 + lane] = (float)v; }
+  MPC_HD double getK(int k, int j) const {
+    if (GAINS_IN_LDS) return (double)lk[(k * GK_N + j) * 64 + lane];
+    return (double)fptr(k, F_GK)[j * 64 + lane];
+  }
+  MPC_HD void setK(int k, int j, double v) const {
+    if (GAINS_IN_LDS) lk[(k * GK_N + j) * 64 + lane] = (float)v;
+    else fptr(k, F_GK)[j * 64 + lane] = (float)v;
+  }
+  MPC_HD double getF(int k, int j) const {
+    if (GAINS_IN_LDS) return lf[(k * GF_N + j) * 64 + lane];
+    return tile[(k * STAGE + F_GF + j) * 64 + lane];
+  }
+  MPC_HD void setF(int k, int j, double v) const {
+    if (GAINS_IN_LDS) lf[(k * GF_N + j) * 64 + lane] = v;
+    else tile[(k * STAGE + F_GF + j) * 64 + lane] = v;
+  }
 };
+#endif
 
 /* ---- light-weight math (same code on device and in the test-only host build) ---- */
 /* reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the barrier terms need dozens of 1/slack
@@ -113,6 +163,8 @@ MPC_HD double frcp(double x) {
   return 1.0 / x;
 #endif
 }
+/* the value a float store would keep (direction entries are stored in fp32) */
+MPC_HD double f32r(double x) { return (double)(float)x; }
 /* x^p for the line-search switching heuristics only (thresholds, not results): single precision */
 MPC_HD double hpow(double x, double p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -177,11 +229,12 @@ struct Eval {
   bool ok;
 };
 
-#if defined(__HIPCC__) || defined(__clang__)
-#define MPC_UNROLL _Pragma("unroll")
-#else
-#define MPC_UNROLL _Pragma("GCC unroll 8")
-#endif
+/* linearisation of one stage at (s_k, u_k) and its residual c_{k+1} = s_{k+1} - F(s_k, u_k) */
+struct Lin {
+  double sp, cp, se, ce;   /* sin/cos of psi_k and epsi_k */
+  double fp, g1, h3, fpp;  /* f'(x_k), f''/(1+f'^2), d/dx of that, f'' */
+  double c[6];
+};
 
 template <class WS>
 struct Solver {
@@ -193,9 +246,9 @@ struct Solver {
   /* bounds */
   double vl, vu, dl, du, al, au;
   int M;       /* number of stages = N-1 */
-  double dt, dtLf;
+  double dt, dtLf, iLf, psi_start;
   /* interior-point state */
-  int cur;     /* slot of the current iterate / model cache */
+  int cur;     /* slot of the current iterate */
   double mu, tau, df;
   Eval E;
   /* direction summary */
@@ -211,9 +264,6 @@ struct Solver {
   MPC_HD Solver(const MpcParams &p, WS w) : P(p), ws(w) {}
 
   MPC_HD int it(int slot) const { return slot ? IT1 : IT0; }
-  /* the model cache needs no second slot: backward/forward/costate of an iteration have all run
-   * before the trial point overwrites it, and a rejected trial is simply overwritten by the next */
-  MPC_HD int mc(int) const { return MC0; }
 
   /* ---- road polynomial: RoadGeometry::centerY / orientation, utils.h:28-47 */
   MPC_HD void poly(double x, double &f, double &fp, double &fpp, double &fppp) const {
@@ -224,28 +274,27 @@ struct Solver {
     fppp = 24.0 * c4 * x + 6.0 * c3;
   }
 
-  /* model of stage k at (s,u): trig cache + F(s,u), MPC.cpp:142-152 */
-  MPC_HD void model(const double *s, double delta, double a, double *m8, double *F) const {
-    double sp, cp, se, ce;
-    fsincos(s[2], &sp, &cp);
-    fsincos(s[5], &se, &ce);
+  /* Stage model at (s,u), MPC.cpp:142-152, and the residual against the successor state sn.
+   * Recomputed wherever it is needed (see the layout comment). */
+  MPC_HD void linearise(const double *s, double delta, double a, const double *sn, Lin &L) const {
+    fsincos(s[2], &L.sp, &L.cp);
+    fsincos(s[5], &L.se, &L.ce);
     double f, fp, fpp, fppp;
     poly(s[0], f, fp, fpp, fppp);
     const double q1 = 1.0 + fp * fp, iq1 = frcp(q1);
-    m8[MC_SP] = sp; m8[MC_CP] = cp; m8[MC_SE] = se; m8[MC_CE] = ce; m8[MC_FP] = fp;
-    m8[MC_G1] = fpp * iq1;
-    m8[MC_H3] = (fppp * q1 - 2.0 * fp * fpp * fpp) * (iq1 * iq1);
-    m8[MC_FPP] = fpp;
+    L.fp = fp;
+    L.g1 = fpp * iq1;
+    L.h3 = (fppp * q1 - 2.0 * fp * fpp * fpp) * (iq1 * iq1);
+    L.fpp = fpp;
     const double vdt = s[3] * dt;
     const double psin = s[2] + delta * vdt * iLf;
-    F[0] = s[0] + cp * vdt;
-    F[1] = s[1] + sp * vdt;
-    F[2] = psin;
-    F[3] = s[3] + a * dt;
-    F[4] = (f - s[1]) + se * vdt;
-    F[5] = psin - atan(fp);
+    L.c[0] = sn[0] - (s[0] + L.cp * vdt);
+    L.c[1] = sn[1] - (s[1] + L.sp * vdt);
+    L.c[2] = sn[2] - psin;
+    L.c[3] = sn[3] - (s[3] + a * dt);
+    L.c[4] = sn[4] - ((f - s[1]) + L.se * vdt);
+    L.c[5] = sn[5] - (psin - atan(fp));
   }
-  double iLf;
 
   /* cost + barrier terms of one state s_k (k>=1): Hessian diagonal and gradient */
   MPC_HD void state_terms(double psi, double v, double c, double e, double zlp, double zup, double zlv,
@@ -263,13 +312,23 @@ struct Solver {
     gc = df * 2.0 * wc * c;
   }
 
+  MPC_HD void load_state(int k, int I, double *s) const {   /* s_k; k = 0 is the fixed initial state */
+    if (k == 0) {
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) s[i] = st[i];
+    } else {
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) s[i] = ws.it(k - 1, I + F_S + i);
+    }
+  }
+
   /* ------------------------------------------------------------------ */
   /* Riccati backward sweep: gains K_k, kff_k for every stage.           */
   /* Returns false when some R~_k is not positive definite (wrong        */
   /* inertia): the caller raises the regularisation dw and repeats.      */
   /* ------------------------------------------------------------------ */
   MPC_HD bool backward(double dw) {
-    const int I = it(cur), C = mc(cur);
+    const int I = it(cur);
     double Pm[6][6], p[6], Pcc, pc; /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1 */
     MPC_UNROLL
     for (int i = 0; i < 6; i++) {
@@ -277,35 +336,36 @@ struct Solver {
       MPC_UNROLL
       for (int j = 0; j < 6; j++) Pm[i][j] = 0;
     }
+    const double rsc = lsm ? 0.0 : -1.0;             /* constraint right-hand side: -c, or 0 for the LS system */
+    const double hxy = (lsm ? 1.0 : 0.0) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
+    double sn[6];                                    /* s_{k+1} */
+    load_state(M, I, sn);
     {
       const int ks = M - 1;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
-                  ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
-                  Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      const double hxy = (lsm ? 1.0 : 0.0) + dw;   /* x and y carry no cost: only the LS identity / regularisation */
+      state_terms(sn[2], sn[3], sn[4], sn[5], ws.it(ks, I + F_ZL + 0), ws.it(ks, I + F_ZU + 0), ws.it(ks, I + F_ZL + 1),
+                  ws.it(ks, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       Pm[0][0] = hxy; Pm[1][1] = hxy; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
       Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
     }
-    const double rsc = lsm ? 0.0 : -1.0;             /* constraint right-hand side: -c, or 0 for the LS system */
-    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     for (int k = M - 1; k >= 0; --k) {
       /* ---- linearisation of stage k ---- */
-      double v, psi_k = 0, c_k = 0, e_k = 0, zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
-      if (k == 0) { v = st[3]; }
-      else {
-        psi_k = ws(k - 1, I + F_S + 2); v = ws(k - 1, I + F_S + 3); c_k = ws(k - 1, I + F_S + 4); e_k = ws(k - 1, I + F_S + 5);
-        zlp = ws(k - 1, I + F_ZL + 0); zup = ws(k - 1, I + F_ZU + 0); zlv = ws(k - 1, I + F_ZL + 1); zuv = ws(k - 1, I + F_ZU + 1);
-        delprev = ws(k - 1, I + F_U + 0);
+      double sk[6];
+      load_state(k, I, sk);
+      double zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
+      if (k > 0) {
+        zlp = ws.it(k - 1, I + F_ZL + 0); zup = ws.it(k - 1, I + F_ZU + 0); zlv = ws.it(k - 1, I + F_ZL + 1); zuv = ws.it(k - 1, I + F_ZU + 1);
+        delprev = ws.it(k - 1, I + F_U + 0);
       }
-      const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
-      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
-      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
-      const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
-      const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
-      const double zld = ws(k, I + F_ZL + 2), zud = ws(k, I + F_ZU + 2), zla = ws(k, I + F_ZL + 3), zua = ws(k, I + F_ZU + 3);
-      const double r0 = rsc * ws(k, C + MC_C + 0), r1 = rsc * ws(k, C + MC_C + 1), r2 = rsc * ws(k, C + MC_C + 2);
-      const double r3 = rsc * ws(k, C + MC_C + 3), rc = rsc * ws(k, C + MC_C + 4), r4 = rsc * ws(k, C + MC_C + 5);
+      const double v = sk[3];
+      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
+      const double lx = ws.it(k, I + F_LAM + 0), ly = ws.it(k, I + F_LAM + 1), lp = ws.it(k, I + F_LAM + 2);
+      const double lc = ws.it(k, I + F_LAM + 4), le = ws.it(k, I + F_LAM + 5);
+      const double zld = ws.it(k, I + F_ZL + 2), zud = ws.it(k, I + F_ZU + 2), zla = ws.it(k, I + F_ZL + 3), zua = ws.it(k, I + F_ZU + 3);
+      Lin L;
+      linearise(sk, delta, acc, sn, L);
+      const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+      const double r0 = rsc * L.c[0], r1 = rsc * L.c[1], r2 = rsc * L.c[2], r3 = rsc * L.c[3], rc = rsc * L.c[4], r4 = rsc * L.c[5];
       const double vdt = v * dt;
       const double Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
       const double Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
@@ -353,8 +413,8 @@ struct Solver {
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
         const double idet = frcp(det);
-        ws(0, F_G + 12) = -(Raa * rt_d - Rda * rt_a) * idet;
-        ws(0, F_G + 13) = -(-Rda * rt_d + Rdd * rt_a) * idet;
+        ws.setF(0, 0, -(Raa * rt_d - Rda * rt_a) * idet);
+        ws.setF(0, 1, -(-Rda * rt_d + Rdd * rt_a) * idet);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -418,15 +478,15 @@ struct Solver {
       for (int j = 0; j < 6; j++) {
         Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
         Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
-        ws(k, F_G + j) = Kd[j];
-        ws(k, F_G + 6 + j) = Ka[j];
+        ws.setK(k, j, Kd[j]);
+        ws.setK(k, 6 + j, Ka[j]);
       }
       const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
-      ws(k, F_G + 12) = kfd;
-      ws(k, F_G + 13) = kfa;
+      ws.setF(k, 0, kfd);
+      ws.setF(k, 1, kfa);
       /* ---- value function of stage k ---- */
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(psi_k, v, c_k, e_k, zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
         MPC_UNROLL
@@ -440,6 +500,8 @@ struct Solver {
       Pm[0][0] += hxy; Pm[1][1] += hxy; Pm[2][2] += Hpp + dw; Pm[3][3] += Hvv + dw; Pm[4][4] += Hee + dw;
       p[2] += gp; p[3] += gv; p[4] += ge;
       Pcc = Hcc + dw; pc = gc;
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sn[i] = sk[i];
     }
 #undef MPC_GT
     return true;
@@ -449,42 +511,49 @@ struct Solver {
   /* forward sweep: Newton direction ds, du; step limits; dphi           */
   /* ------------------------------------------------------------------ */
   MPC_HD void forward() {
-    const int I = it(cur), C = mc(cur);
+    const int I = it(cur);
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
     double ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
     double rmax = 0.0, rzmax = 0.0;                 /* largest step ratios: alpha = min(1, tau / ratio) */
     const double rsc = lsm ? 0.0 : 1.0;
     dphi = 0.0; dxinf = 0.0; xinf = 0.0;
+    double sk[6];
+    load_state(0, I, sk);
     for (int k = 0; k < M; ++k) {
-      const double v = (k == 0) ? st[3] : ws(k - 1, I + F_S + 3);
-      const double delta = ws(k, I + F_U + 0), acc = ws(k, I + F_U + 1);
-      double dd = ws(k, F_G + 12), da = ws(k, F_G + 13);
+      double sn[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sn[i] = ws.it(k, I + F_S + i);
+      const double v = sk[3];
+      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
+      Lin L;
+      linearise(sk, delta, acc, sn, L);
+      double dd = ws.getF(k, 0), da = ws.getF(k, 1);
       if (k > 0) {
-        dd += ws(k, F_G + 0) * d0 + ws(k, F_G + 1) * d1 + ws(k, F_G + 2) * d2 + ws(k, F_G + 3) * d3 +
-              ws(k, F_G + 4) * d5 + ws(k, F_G + 5) * ddprev;
-        da += ws(k, F_G + 6) * d0 + ws(k, F_G + 7) * d1 + ws(k, F_G + 8) * d2 + ws(k, F_G + 9) * d3 +
-              ws(k, F_G + 10) * d5 + ws(k, F_G + 11) * ddprev;
+        dd += ws.getK(k, 0) * d0 + ws.getK(k, 1) * d1 + ws.getK(k, 2) * d2 + ws.getK(k, 3) * d3 + ws.getK(k, 4) * d5 +
+              ws.getK(k, 5) * ddprev;
+        da += ws.getK(k, 6) * d0 + ws.getK(k, 7) * d1 + ws.getK(k, 8) * d2 + ws.getK(k, 9) * d3 + ws.getK(k, 10) * d5 +
+              ws.getK(k, 11) * ddprev;
       }
-      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
-      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1);
       const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
-      const double n0 = d0 - vdt * sp * d2 + dt * cp * d3 - rsc * ws(k, C + MC_C + 0);
-      const double n1 = d1 + vdt * cp * d2 + dt * sp * d3 - rsc * ws(k, C + MC_C + 1);
-      const double n2 = d2 + Apv * d3 + Bp * dd - rsc * ws(k, C + MC_C + 2);
-      const double n3 = d3 + dt * da - rsc * ws(k, C + MC_C + 3);
-      const double n4 = fp * d0 - d1 + dt * se * d3 + vdt * ce * d5 - rsc * ws(k, C + MC_C + 4);
-      const double n5 = -g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * ws(k, C + MC_C + 5);
-      ws(k, F_D + 0) = n0; ws(k, F_D + 1) = n1; ws(k, F_D + 2) = n2; ws(k, F_D + 3) = n3;
-      ws(k, F_D + 4) = n4; ws(k, F_D + 5) = n5; ws(k, F_D + 6) = dd; ws(k, F_D + 7) = da;
+      const double n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
+      const double n1 = d1 + vdt * L.cp * d2 + dt * L.sp * d3 - rsc * L.c[1];
+      const double n2 = d2 + Apv * d3 + Bp * dd - rsc * L.c[2];
+      const double n3 = d3 + dt * da - rsc * L.c[3];
+      const double n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
+      const double n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
+      ws.setD(k, D_S + 0, n0); ws.setD(k, D_S + 1, n1); ws.setD(k, D_S + 2, n2); ws.setD(k, D_S + 3, n3);
+      ws.setD(k, D_S + 4, n4); ws.setD(k, D_S + 5, n5); ws.setD(k, D_U + 0, dd); ws.setD(k, D_U + 1, da);
+      /* what the trial point will actually add (the direction is stored in fp32): step limits and the
+       * directional derivative are taken on these values so that they are consistent with trial() */
+      const double q2 = f32r(n2), q3 = f32r(n3), q4 = f32r(n4), q5 = f32r(n5), qd = f32r(dd), qa = f32r(da);
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
-      const double psn = ws(k, I + F_S + 2), vn = ws(k, I + F_S + 3);
-      const double xs[4] = {psn, vn, delta, acc};
+      const double xs[4] = {sn[2], sn[3], delta, acc};
       const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
-      const double dx[4] = {n2, n3, dd, da};
+      const double dx[4] = {q2, q3, qd, qa};
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
         const double isl = frcp(xs[b] - lo[b]), isu = frcp(hi[b] - xs[b]);
-        const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
+        const double zl = ws.it(k, I + F_ZL + b), zu = ws.it(k, I + F_ZU + b);
         rmax = fmax(rmax, fmax(-dx[b] * isl, dx[b] * isu));
         const double dzl = mu * isl - zl - zl * isl * dx[b];
         const double dzu = mu * isu - zu + zu * isu * dx[b];
@@ -492,14 +561,15 @@ struct Solver {
         dphi += mu * (isu - isl) * dx[b];
       }
       /* objective part of the directional derivative */
-      const double cn = ws(k, I + F_S + 4), en = ws(k, I + F_S + 5);
-      double g = 2.0 * wc * cn * n4 + 2.0 * we * en * n5 + 2.0 * wv * (vn - vref) * n3 + 2.0 * wd * delta * dd;
-      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (dd - ddprev);
+      double g = 2.0 * wc * sn[4] * q4 + 2.0 * we * sn[5] * q5 + 2.0 * wv * (sn[3] - vref) * q3 + 2.0 * wd * delta * qd;
+      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (qd - f32r(ddprev));
       dphi += df * g;
       dxinf = fmax(dxinf, fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
                                fmax(fmax(fabs(n4), fabs(n5)), fmax(fabs(dd), fabs(da)))));
-      xinf = fmax(xinf, fmax(fmax(fabs(ws(k, I + F_S + 0)), fabs(ws(k, I + F_S + 1))), fmax(fabs(vn), fabs(cn))));
+      xinf = fmax(xinf, fmax(fmax(fabs(sn[0]), fabs(sn[1])), fmax(fabs(sn[3]), fabs(sn[4]))));
       d0 = n0; d1 = n1; d2 = n2; d3 = n3; d5 = n5; ddprev = dd; delprev = delta;
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sk[i] = sn[i];
     }
     /* fraction to the boundary, W&B eq. (15): alpha = min(1, tau / max ratio) */
     amax = (rmax > tau) ? tau / rmax : 1.0;
@@ -511,41 +581,45 @@ struct Solver {
   /* (the state rows of the Newton system, solved for lam+)               */
   /* ------------------------------------------------------------------ */
   MPC_HD void costate(double dw) {
-    const int I = it(cur), C = mc(cur);
+    const int I = it(cur);
+    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     double L0, L1, L2, L3, L4, L5; /* lam+_{k+1}: x,y,psi,v,c,e */
+    double sn[6];
+    load_state(M, I, sn);
     {
       const int ks = M - 1;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(ws(ks, I + F_S + 2), ws(ks, I + F_S + 3), ws(ks, I + F_S + 4), ws(ks, I + F_S + 5),
-                  ws(ks, I + F_ZL + 0), ws(ks, I + F_ZU + 0), ws(ks, I + F_ZL + 1), ws(ks, I + F_ZU + 1),
-                  Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      const double hxy = (lsm ? 1.0 : 0.0) + dw;
-      L0 = -(hxy * ws(ks, F_D + 0));
-      L1 = -(hxy * ws(ks, F_D + 1));
-      L2 = -(gp + (Hpp + dw) * ws(ks, F_D + 2));
-      L3 = -(gv + (Hvv + dw) * ws(ks, F_D + 3));
-      L4 = -(gc + (Hcc + dw) * ws(ks, F_D + 4));
-      L5 = -(ge + (Hee + dw) * ws(ks, F_D + 5));
-      ws(ks, F_D + 8) = L0 - ws(ks, I + F_LAM + 0); ws(ks, F_D + 9) = L1 - ws(ks, I + F_LAM + 1);
-      ws(ks, F_D + 10) = L2 - ws(ks, I + F_LAM + 2); ws(ks, F_D + 11) = L3 - ws(ks, I + F_LAM + 3);
-      ws(ks, F_D + 12) = L4 - ws(ks, I + F_LAM + 4); ws(ks, F_D + 13) = L5 - ws(ks, I + F_LAM + 5);
+      state_terms(sn[2], sn[3], sn[4], sn[5], ws.it(ks, I + F_ZL + 0), ws.it(ks, I + F_ZU + 0), ws.it(ks, I + F_ZL + 1),
+                  ws.it(ks, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      L0 = -(hxy * ws.getD(ks, D_S + 0));
+      L1 = -(hxy * ws.getD(ks, D_S + 1));
+      L2 = -(gp + (Hpp + dw) * ws.getD(ks, D_S + 2));
+      L3 = -(gv + (Hvv + dw) * ws.getD(ks, D_S + 3));
+      L4 = -(gc + (Hcc + dw) * ws.getD(ks, D_S + 4));
+      L5 = -(ge + (Hee + dw) * ws.getD(ks, D_S + 5));
+      ws.setD(ks, D_LAM + 0, L0 - ws.it(ks, I + F_LAM + 0)); ws.setD(ks, D_LAM + 1, L1 - ws.it(ks, I + F_LAM + 1));
+      ws.setD(ks, D_LAM + 2, L2 - ws.it(ks, I + F_LAM + 2)); ws.setD(ks, D_LAM + 3, L3 - ws.it(ks, I + F_LAM + 3));
+      ws.setD(ks, D_LAM + 4, L4 - ws.it(ks, I + F_LAM + 4)); ws.setD(ks, D_LAM + 5, L5 - ws.it(ks, I + F_LAM + 5));
     }
-    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     for (int k = M - 1; k >= 1; --k) {
-      const double psi = ws(k - 1, I + F_S + 2), v = ws(k - 1, I + F_S + 3), c = ws(k - 1, I + F_S + 4), e = ws(k - 1, I + F_S + 5);
-      const double delta = ws(k, I + F_U + 0);
-      const double sp = ws(k, C + MC_SP), cp = ws(k, C + MC_CP), se = ws(k, C + MC_SE), ce = ws(k, C + MC_CE);
-      const double fp = ws(k, C + MC_FP), g1 = ws(k, C + MC_G1), h3 = ws(k, C + MC_H3), fpp = ws(k, C + MC_FPP);
-      const double lx = ws(k, I + F_LAM + 0), ly = ws(k, I + F_LAM + 1), lp = ws(k, I + F_LAM + 2);
-      const double lc = ws(k, I + F_LAM + 4), le = ws(k, I + F_LAM + 5);
-      const double dxk = ws(k - 1, F_D + 0), dyk = ws(k - 1, F_D + 1), dpk = ws(k - 1, F_D + 2), dvk = ws(k - 1, F_D + 3);
-      const double dck = ws(k - 1, F_D + 4), dek = ws(k - 1, F_D + 5), ddk = ws(k, F_D + 6);
-      const double lo0 = ws(k - 1, I + F_LAM + 0), lo1 = ws(k - 1, I + F_LAM + 1), lo2 = ws(k - 1, I + F_LAM + 2);
-      const double lo3 = ws(k - 1, I + F_LAM + 3), lo4 = ws(k - 1, I + F_LAM + 4), lo5 = ws(k - 1, I + F_LAM + 5);
+      double sk[6];
+      load_state(k, I, sk);
+      const double v = sk[3];
+      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
+      Lin L;
+      linearise(sk, delta, acc, sn, L);   /* the residual part is unused here and is eliminated */
+      const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+      const double lx = ws.it(k, I + F_LAM + 0), ly = ws.it(k, I + F_LAM + 1), lp = ws.it(k, I + F_LAM + 2);
+      const double lc = ws.it(k, I + F_LAM + 4), le = ws.it(k, I + F_LAM + 5);
+      const double dxk = ws.getD(k - 1, D_S + 0), dyk = ws.getD(k - 1, D_S + 1), dpk = ws.getD(k - 1, D_S + 2);
+      const double dvk = ws.getD(k - 1, D_S + 3), dck = ws.getD(k - 1, D_S + 4), dek = ws.getD(k - 1, D_S + 5);
+      const double ddk = ws.getD(k, D_U + 0);
+      const double lo0 = ws.it(k - 1, I + F_LAM + 0), lo1 = ws.it(k - 1, I + F_LAM + 1), lo2 = ws.it(k - 1, I + F_LAM + 2);
+      const double lo3 = ws.it(k - 1, I + F_LAM + 3), lo4 = ws.it(k - 1, I + F_LAM + 4), lo5 = ws.it(k - 1, I + F_LAM + 5);
       const double vdt = v * dt, Apv = delta * dtLf;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(psi, v, c, e, ws(k - 1, I + F_ZL + 0), ws(k - 1, I + F_ZU + 0), ws(k - 1, I + F_ZL + 1),
-                  ws(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      state_terms(sk[2], v, sk[4], sk[5], ws.it(k - 1, I + F_ZL + 0), ws.it(k - 1, I + F_ZU + 0), ws.it(k - 1, I + F_ZL + 1),
+                  ws.it(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       /* curvature of stage k */
       const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
       const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
@@ -558,8 +632,10 @@ struct Solver {
       const double n4 = -gc - (Hcc + dw) * dck;
       const double n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * dek - Hev * dvk;
       L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
-      ws(k - 1, F_D + 8) = L0 - lo0; ws(k - 1, F_D + 9) = L1 - lo1; ws(k - 1, F_D + 10) = L2 - lo2;
-      ws(k - 1, F_D + 11) = L3 - lo3; ws(k - 1, F_D + 12) = L4 - lo4; ws(k - 1, F_D + 13) = L5 - lo5;
+      ws.setD(k - 1, D_LAM + 0, L0 - lo0); ws.setD(k - 1, D_LAM + 1, L1 - lo1); ws.setD(k - 1, D_LAM + 2, L2 - lo2);
+      ws.setD(k - 1, D_LAM + 3, L3 - lo3); ws.setD(k - 1, D_LAM + 4, L4 - lo4); ws.setD(k - 1, D_LAM + 5, L5 - lo5);
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sn[i] = sk[i];
     }
   }
 
@@ -568,7 +644,7 @@ struct Solver {
   /* residuals, objective, barrier, and the optimality error pieces.      */
   /* ------------------------------------------------------------------ */
   MPC_HD Eval trial(double alpha, double alpha_z) {
-    const int I = it(cur), J = it(1 - cur), CJ = mc(1 - cur);
+    const int I = it(cur), J = it(1 - cur);
     Eval R;
     R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.ok = true;
     double s[6] = {st[0], st[1], st[2], st[3], st[4], st[5]};
@@ -577,34 +653,28 @@ struct Solver {
     double rdel_prev = 0, delprev = 0;
     const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
     for (int k = 0; k < M; ++k) {
-      const double delo = ws(k, I + F_U + 0), acco = ws(k, I + F_U + 1);
-      const double ddel = ws(k, F_D + 6), dacc = ws(k, F_D + 7);
+      const double delo = ws.it(k, I + F_U + 0), acco = ws.it(k, I + F_U + 1);
+      const double ddel = ws.getD(k, D_U + 0), dacc = ws.getD(k, D_U + 1);
       const double delta = delo + alpha * ddel;
       const double acc = acco + alpha * dacc;
       double so[6], dso[6], sn[6], ln[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
-        so[i] = ws(k, I + F_S + i); dso[i] = ws(k, F_D + i);
+        so[i] = ws.it(k, I + F_S + i); dso[i] = ws.getD(k, D_S + i);
         sn[i] = so[i] + alpha * dso[i];
-        ln[i] = ws(k, I + F_LAM + i) + alpha * ws(k, F_D + 8 + i);
+        ln[i] = ws.it(k, I + F_LAM + i) + alpha * ws.getD(k, D_LAM + i);
       }
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
-        ws(k, J + F_S + i) = sn[i];
-        ws(k, J + F_LAM + i) = ln[i];
+        ws.it(k, J + F_S + i) = sn[i];
+        ws.it(k, J + F_LAM + i) = ln[i];
         R.lsum += fabs(ln[i]);
       }
-      ws(k, J + F_U + 0) = delta; ws(k, J + F_U + 1) = acc;
-      double m8[8], F[6];
-      model(s, delta, acc, m8, F);
+      ws.it(k, J + F_U + 0) = delta; ws.it(k, J + F_U + 1) = acc;
+      Lin L;
+      linearise(s, delta, acc, sn, L);
       MPC_UNROLL
-      for (int i = 0; i < 8; i++) ws(k, CJ + i) = m8[i];
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) {
-        const double c = sn[i] - F[i];
-        ws(k, CJ + MC_C + i) = c;
-        R.theta += fabs(c); R.cinf = fmax(R.cinf, fabs(c));
-      }
+      for (int i = 0; i < 6; i++) { R.theta += fabs(L.c[i]); R.cinf = fmax(R.cinf, fabs(L.c[i])); }
       /* duals of psi_{k+1}, v_{k+1}, delta_k, a_k */
       const double xo[4] = {so[2], so[3], delo, acco};
       const double xn[4] = {sn[2], sn[3], delta, acc};
@@ -614,7 +684,7 @@ struct Solver {
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
         const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
-        const double zl = ws(k, I + F_ZL + b), zu = ws(k, I + F_ZU + b);
+        const double zl = ws.it(k, I + F_ZL + b), zu = ws.it(k, I + F_ZU + b);
         const double dzl = mu * islo - zl - zl * islo * dxb[b];
         const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
         const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
@@ -625,7 +695,7 @@ struct Solver {
         a = fmax(fmin(a, ksm * isl), ksi * isl);
         c = fmax(fmin(c, ksm * isu), ksi * isu);
         zln[b] = a; zun[b] = c;
-        ws(k, J + F_ZL + b) = a; ws(k, J + F_ZU + b) = c;
+        ws.it(k, J + F_ZL + b) = a; ws.it(k, J + F_ZU + b) = c;
         R.zsum += a + c;
         const double pl = sl * a, pu = su * c;
         R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
@@ -641,14 +711,13 @@ struct Solver {
       const double v = s[3], vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const double l25 = ln[2] + ln[5];
       if (k > 0) {
-        const double r0 = lamk[0] - (ln[0] + m8[MC_FP] * ln[4] - m8[MC_G1] * ln[5]);
+        const double r0 = lamk[0] - (ln[0] + L.fp * ln[4] - L.g1 * ln[5]);
         const double r1 = lamk[1] - (ln[1] - ln[4]);
-        const double r2 = lamk[2] - (-vdt * m8[MC_SP] * ln[0] + vdt * m8[MC_CP] * ln[1] + l25) - zs0 + zs1;
+        const double r2 = lamk[2] - (-vdt * L.sp * ln[0] + vdt * L.cp * ln[1] + l25) - zs0 + zs1;
         const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] -
-                          (dt * m8[MC_CP] * ln[0] + dt * m8[MC_SP] * ln[1] + Apv * l25 + ln[3] + dt * m8[MC_SE] * ln[4]) -
-                          zs2 + zs3;
+                          (dt * L.cp * ln[0] + dt * L.sp * ln[1] + Apv * l25 + ln[3] + dt * L.se * ln[4]) - zs2 + zs3;
         const double r4 = df * 2.0 * wc * s[4] + lamk[4];
-        const double r5 = df * 2.0 * we * s[5] + lamk[5] - vdt * m8[MC_CE] * ln[4];
+        const double r5 = df * 2.0 * we * s[5] + lamk[5] - vdt * L.ce * ln[4];
         R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
         /* finish the delta_{k-1} row now that delta_k is known */
         R.dinf = fmax(R.dinf, fabs(rdel_prev - df * 2.0 * wdd * ddl));
@@ -707,18 +776,17 @@ struct Solver {
     else { fth3 = th; fph3 = ph; }
   }
 
-  double psi_start;
   /* the start point of MPC.cpp:207-210 (zeros), pushed into the interior, in iterate slot 0 */
   MPC_HD void start_point() {
     for (int k = 0; k < M; ++k) {
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) { ws(k, IT0 + F_S + i) = 0.0; ws(k, IT0 + F_LAM + i) = 0.0; }
-      ws(k, IT0 + F_S + 2) = psi_start;
-      ws(k, IT0 + F_U + 0) = 0.0; ws(k, IT0 + F_U + 1) = 0.0;
+      for (int i = 0; i < 6; i++) { ws.it(k, IT0 + F_S + i) = 0.0; ws.it(k, IT0 + F_LAM + i) = 0.0; }
+      ws.it(k, IT0 + F_S + 2) = psi_start;
+      ws.it(k, IT0 + F_U + 0) = 0.0; ws.it(k, IT0 + F_U + 1) = 0.0;
       MPC_UNROLL
-      for (int b = 0; b < 4; b++) { ws(k, IT0 + F_ZL + b) = 1.0; ws(k, IT0 + F_ZU + b) = 1.0; }
+      for (int b = 0; b < 4; b++) { ws.it(k, IT0 + F_ZL + b) = 1.0; ws.it(k, IT0 + F_ZU + b) = 1.0; }
       MPC_UNROLL
-      for (int i = 0; i < D_SZ; i++) ws(k, F_D + i) = 0.0;
+      for (int i = 0; i < D_N; i++) ws.setD(k, i, 0.0);
     }
   }
 
@@ -735,6 +803,7 @@ struct Solver {
     vl = -P.max_speed; vu = P.max_speed; dl = -P.max_steering; du = P.max_steering;
     al = P.max_deceleration; au = P.max_acceleration;
     fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = 0.0;
+    lsm = false; cur = 0; iters = 0; n_reg = 0; nf = 0; E.f = 0.0;
     /* Branch outcomes at the start point xi = (state at index 0, zeros elsewhere):
      * for i >= 1 every variable is 0, so (MPC.cpp:72-112)
      *   |cte_i| < ctePanic  -> w[0] unless ctePanic <= 0
@@ -775,122 +844,148 @@ struct Solver {
   /* the interior-point iteration                                         */
   /* ------------------------------------------------------------------ */
   MPC_HD int solve() {
-    int status = solve_from_start(true);
-    if (status == MPC_STATUS_LINESEARCH) {
-      /* IPOPT would enter its feasibility-restoration phase here.  Stand-in (same as the oracle's):
-       * restart from the start point with zero equality multipliers. */
-      const int it1 = iters;
-      start_point();
-      status = solve_from_start(false);
-      iters += it1;
+    int status = MPC_STATUS_LINESEARCH, it_total = 0;
+    /* A line search that runs out of step length is where IPOPT would enter its feasibility-
+     * restoration phase.  Stand-in (same as the oracle's): restart ONCE from the start point with
+     * zero equality multipliers.  (Written as a loop so that the solver body is instantiated once.) */
+    for (int attempt = 0; attempt < 2 && status == MPC_STATUS_LINESEARCH; ++attempt) {
+      if (attempt > 0) start_point();
+      status = solve_from_start(attempt == 0);
+      it_total += iters;
     }
+    iters = it_total;
     return status;
   }
 
+  /* The interior-point loop, written as a small state machine so that each of the four sweeps has
+   * exactly ONE call site (they are force-inlined; several call sites would multiply the code size
+   * and thrash the instruction cache):
+   *   EVAL0     evaluate the start point                       -> trial(0, 0)
+   *   LS        least-squares multiplier start (W&B section 3.6, IPOPT default): one Riccati pass
+   *             with identity Hessian; estimates above constr_mult_init_max = 1000 are discarded
+   *   DIR       convergence test, barrier update, search direction, first trial of the line search
+   *   BACKTRACK further trials of the same line search                                              */
   MPC_HD int solve_from_start(bool ls_start) {
+    enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
     cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
-    E = trial(0.0, 0.0);
-    cur = 1;
-    if (!E.ok) return MPC_STATUS_NUMERIC;
-    /* least-squares start for the equality multipliers (IPOPT default; W&B section 3.6): one extra
-     * Riccati pass with identity Hessian.  Estimates above constr_mult_init_max = 1000 are discarded. */
-    if (ls_start) {
-      lsm = true;
-      const bool okb = backward(0.0);
-      double lmax = 0.0;
-      if (okb) {
-        forward();
-        costate(0.0);
-        for (int k = 0; k < M; ++k) {
-          MPC_UNROLL
-          for (int i = 0; i < 6; i++) lmax = fmax(lmax, fabs(ws(k, F_D + 8 + i)));
-        }
-      }
-      lsm = false;
-      const bool use = okb && (lmax <= 1000.0);
-      for (int k = 0; k < M; ++k) {
-        MPC_UNROLL
-        for (int i = 0; i < 8; i++) ws(k, F_D + i) = 0.0;
-        if (!use) {
-          MPC_UNROLL
-          for (int i = 0; i < 6; i++) ws(k, F_D + 8 + i) = 0.0;
-        }
-      }
-      if (use) {
-        E = trial(1.0, 0.0);          /* lam <- lam_LS; primal point and bound duals unchanged */
-        cur = 1 - cur;
-        if (!E.ok) return MPC_STATUS_NUMERIC;
-      }
-    }
-    const double theta_max = 1e4 * fmax(1.0, E.theta), theta_min = 1e-4 * fmax(1.0, E.theta);
+    int phase = PH_EVAL0, iter = 0;
+    double alpha = 0.0, alpha_z = 0.0;
+    double theta_max = 0.0, theta_min = 0.0, dw_last = 0.0;
+    double theta_k = 0.0, phi_k = 0.0, pth = 0.0, pdp = 0.0, amin = 0.0;   /* line-search state */
+    bool tiny = false;
     const double mu_floor = P.tol / 10.0;
-    double dw_last = 0.0;
-    for (int iter = 0;; ++iter) {
-      iters = iter;
-      const double E0 = kkt_error(E, 0.0);
-      if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
-      if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
-      if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
-      /* barrier update, W&B eq. (7) */
-      while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
-        mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
-        tau = fmax(IpmConst::tau_min, 1.0 - mu);
-        nf = 0;
-      }
-      /* search direction with inertia correction, W&B section 3.1 */
-      double dw = 0.0;
-      int tries = 0;
-      while (!backward(dw)) {
-        if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
-        else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
-        if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
-      }
-      if (dw > 0.0) { dw_last = dw; n_reg++; }
-      forward();
-      costate(dw);
-#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-      printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e dw=%.1e amax=%.3g az=%.3g dphi=%.3e nf=%d\n", iter,
-             E.f, E.theta, E.dinf, E.cmin, E.cmax, mu, E0, dw, amax, az, dphi, nf);
-#endif
-      /* filter line search, W&B algorithm A */
-      const double theta_k = E.theta, phi_k = df * E.f - mu * E.L;
-      const double pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
-      const double pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
-      double amin;
-      if (dphi < 0.0) {
-        const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
-        amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
-      } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
-      const bool tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
-      double alpha = amax;
-      bool accepted = false, ftype = false;
-      Eval T;
-      for (;;) {
-        T = trial(alpha, az);
-        if (tiny) { accepted = T.ok; ftype = true; break; }
-        if (T.ok) {
-          const double phi_t = df * T.f - mu * T.L;
-          const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
-          if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
-            const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
-            const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
-            if (theta_k <= theta_min && sw) {
-              if (armijo) accepted = true;
-            } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
-                       phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
-              accepted = true;
-            }
-            ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
+    for (;;) {
+      if (phase == PH_LS || phase == PH_DIR) {
+        if (phase == PH_DIR) {
+          iters = iter;
+          const double E0 = kkt_error(E, 0.0);
+          if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
+          if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
+          if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
+          /* barrier update, W&B eq. (7) */
+          while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
+            mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
+            tau = fmax(IpmConst::tau_min, 1.0 - mu);
+            nf = 0;
           }
+#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+          printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
+                 E.dinf, E.cmin, E.cmax, mu, E0, nf);
+#endif
         }
-        if (accepted) break;
-        alpha *= 0.5;
-        if (alpha < amin) break;
+        lsm = (phase == PH_LS);
+        /* search direction with inertia correction, W&B section 3.1 */
+        double dw = 0.0;
+        int tries = 0;
+        bool okb = true;
+        while (!backward(dw)) {
+          if (lsm) { okb = false; break; }
+          if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
+          else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
+          if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
+        }
+        if (okb) {
+          forward();
+          costate(dw);
+        }
+        if (phase == PH_LS) {
+          double lmax = 0.0;
+          if (okb) {
+            for (int k = 0; k < M; ++k) {
+              MPC_UNROLL
+              for (int i = 0; i < 6; i++) lmax = fmax(lmax, fabs(ws.getD(k, D_LAM + i)));
+            }
+          }
+          lsm = false;
+          const bool use = okb && (lmax <= 1000.0);
+          for (int k = 0; k < M; ++k) {
+            MPC_UNROLL
+            for (int i = 0; i < 8; i++) ws.setD(k, i, 0.0);
+            if (!use) {
+              MPC_UNROLL
+              for (int i = 0; i < 6; i++) ws.setD(k, D_LAM + i, 0.0);
+            }
+          }
+          if (!use) { phase = PH_DIR; continue; }
+          alpha = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
+        } else {
+          if (dw > 0.0) { dw_last = dw; n_reg++; }
+          /* filter line search, W&B algorithm A */
+          theta_k = E.theta; phi_k = df * E.f - mu * E.L;
+          pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
+          pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
+          if (dphi < 0.0) {
+            const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
+            amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
+          } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
+          tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
+          alpha = amax; alpha_z = az;
+        }
       }
-      if (!accepted) return MPC_STATUS_LINESEARCH;
-      if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
-      cur = 1 - cur;
-      E = T;
+      const Eval T = trial(alpha, alpha_z);
+      if (phase == PH_EVAL0) {
+        E = T; cur = 1;
+        if (!E.ok) return MPC_STATUS_NUMERIC;
+        theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
+        phase = ls_start ? PH_LS : PH_DIR;
+        continue;
+      }
+      if (phase == PH_LS) {
+        E = T; cur = 1 - cur;
+        if (!E.ok) return MPC_STATUS_NUMERIC;
+        phase = PH_DIR;
+        continue;
+      }
+      /* acceptance test of the line search */
+      bool accepted = false, ftype = false;
+      if (tiny) { accepted = T.ok; ftype = true; }
+      else if (T.ok) {
+        const double phi_t = df * T.f - mu * T.L;
+        const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
+        if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
+          const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
+          const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
+          if (theta_k <= theta_min && sw) {
+            if (armijo) accepted = true;
+          } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
+                     phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
+            accepted = true;
+          }
+          ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
+        }
+      }
+      if (accepted) {
+        if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
+        cur = 1 - cur;
+        E = T;
+        ++iter;
+        phase = PH_DIR;
+        continue;
+      }
+      if (tiny) return MPC_STATUS_LINESEARCH;
+      alpha *= 0.5;
+      if (alpha < amin) return MPC_STATUS_LINESEARCH;
+      phase = PH_BACKTRACK;
     }
   }
 
@@ -899,14 +994,14 @@ struct Solver {
   MPC_HD void unpack(OutF out, TrajF traj, bool want_traj) const {
     const int I = it(cur);
     MPC_UNROLL
-    for (int i = 0; i < 6; i++) out(i) = ws(0, I + F_S + i);
-    out(6) = ws(0, I + F_U + 0);
-    out(7) = ws(0, I + F_U + 1);
+    for (int i = 0; i < 6; i++) out(i) = ws.it(0, I + F_S + i);
+    out(6) = ws.it(0, I + F_U + 0);
+    out(7) = ws.it(0, I + F_U + 1);
     out(8) = E.f + cost0;
     if (want_traj) {
       const int N = P.N;
       traj(0) = st[0]; traj(N) = st[1];
-      for (int k = 0; k < M; ++k) { traj(k + 1) = ws(k, I + F_S + 0); traj(N + k + 1) = ws(k, I + F_S + 1); }
+      for (int k = 0; k < M; ++k) { traj(k + 1) = ws.it(k, I + F_S + 0); traj(N + k + 1) = ws.it(k, I + F_S + 1); }
     }
   }
 };
@@ -918,11 +1013,7 @@ MPC_HD int solve_instance(const MpcParams &P, WS ws, const double *state6, const
                           double yaw_hi, const double *w12, double *out9, double *traj2N, int *iters_out) {
   Solver<WS> S(P, ws);
   int status = S.setup(state6, coef5, yaw_lo, yaw_hi, w12);
-  if (status == MPC_STATUS_SUCCESS) {
-    status = S.solve();
-  } else {
-    S.cur = 0; S.E.f = 0.0; S.iters = 0;
-  }
+  if (status == MPC_STATUS_SUCCESS) status = S.solve();
   double *o = out9;
   double *t = traj2N;
   S.unpack([o](int i) -> double & { return o[i]; }, [t](int i) -> double & { return t[i]; }, traj2N != nullptr);

@@ -30,18 +30,23 @@ thread_local std::string g_last_error;
   } while (0)
 
 constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchronise */
+constexpr int64_t kLdsPerCu = 160 * 1024;
 
 /*
- * One instance per lane.  Inputs/outputs are [quantity][instance] so that a
- * wave's access to one quantity is a single contiguous 512-byte transaction.
- * The workspace is [stage*field][instance] with the same property.
+ * One instance per lane.  Inputs/outputs are [quantity][instance] so that a wave's access to one
+ * quantity is a single contiguous 512-byte transaction; the workspace is tiled per wave
+ * ([wave][stage*field][lane], see mpc_core.h).  GAINS_IN_LDS: the Riccati gains of all stages
+ * live in the workgroup's LDS (4 KB per stage) instead of the HBM tile; chosen by the launcher when
+ * four workgroups per CU still fit (one wave per SIMD).
  */
+template <bool GAINS_IN_LDS>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const double *__restrict__ state,
     const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
     const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
-    const int64_t ws_stride) {
+    const int64_t tile_doubles) {
+  extern __shared__ double smem[];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
   double st[6], cf[MPC_NCOEF], w[MPC_NW];
@@ -56,12 +61,15 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 #pragma unroll
     for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
   }
-  /* per-wave tile of the workspace; ws_stride = doubles per wave tile */
-  mpc::TiledWorkspace ws{(mpc::gdouble *)(wsbase + (i >> 6) * ws_stride + (i & 63))};
-  mpc::Solver<mpc::TiledWorkspace> S(P, ws);
+  using WS = mpc::TiledWorkspace<GAINS_IN_LDS>;
+  WS ws;
+  ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
+  ws.lane = threadIdx.x;
+  ws.lf = (mpc::ldouble *)smem;                                              /* kff: [stage][2][64] doubles */
+  ws.lk = (mpc::lfloat *)(smem + (int64_t)(P.N - 1) * mpc::GF_N * 64);       /* K:   [stage][12][64] floats */
+  mpc::Solver<WS> S(P, ws);
   int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
-  else { S.cur = 0; S.E.f = 0.0; S.iters = 0; }
   double *o = out + i;
   double *t = traj ? traj + i : nullptr;
   const int64_t l = ld;
@@ -78,6 +86,8 @@ struct MpcHandle {
   int device = 0;
   int64_t max_batch = 0;
   int64_t ws_stride = 0;   /* doubles per wavefront tile of the workspace */
+  bool gains_in_lds = false;
+  size_t lds_bytes = 0;
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   double *ws = nullptr;
   hipStream_t stream = nullptr;
@@ -124,7 +134,10 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   MpcHandle *h = new MpcHandle();
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  h->ws_stride = mpc::workspace_doubles_per_instance(p->N) * 64;       /* doubles per wavefront tile */
+  /* gains in LDS when four one-wave workgroups per CU (one per SIMD) still fit into 160 KB */
+  h->gains_in_lds = 4 * mpc::gains_lds_bytes_per_wave(p->N) <= kLdsPerCu;
+  h->lds_bytes = h->gains_in_lds ? (size_t)mpc::gains_lds_bytes_per_wave(p->N) : 0;
+  h->ws_stride = mpc::workspace_fields_per_instance(p->N, h->gains_in_lds) * 64;   /* doubles per wavefront tile */
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -176,8 +189,12 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(mpc_solve_kernel, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs, yaw_lo,
-                     yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+  if (h->gains_in_lds)
+    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), h->lds_bytes, s, h->params, B, ld, state, coeffs,
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+  else
+    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs,
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;

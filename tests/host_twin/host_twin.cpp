@@ -19,14 +19,14 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
                                    int32_t *iters) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N;
-  std::vector<double> wsbuf((size_t)mpc::workspace_doubles_per_instance(N));
+  std::vector<double> wsbuf((size_t)(N - 1) * mpc::STAGE_SZ_HOST);
   for (int64_t i = 0; i < B; i++) {
     double st[6], cf[MPC_NCOEF], w[MPC_NW], o9[9];
     std::vector<double> tr(2 * N);
     for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
     for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
     for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : p->weights[q];
-    mpc::SoaWorkspace ws{wsbuf.data(), 1};
+    mpc::HostWorkspace ws{wsbuf.data()};
     int it = 0;
     int s = mpc::solve_instance(*p, ws, st, cf, yaw_lo[i], yaw_hi[i], w, o9, traj ? tr.data() : nullptr, &it);
     for (int q = 0; q < 9; q++) out[q * ld + i] = o9[q];
