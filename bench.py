@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--no-traj", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--N", type=int, default=0, help="override Config::N (BASELINE.json configs[3]: 25)")
+    ap.add_argument("--dt", type=float, default=0.0, help="override Config::dt (configs[3]: 0.05)")
+    ap.add_argument("--weights-sweep", action="store_true", help="per-instance Config::weights (configs[4])")
     args = ap.parse_args()
 
     import numpy as np
@@ -68,7 +71,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     golden = os.path.join(ROOT, "tests", "golden")
-    params = pkg.params_from_json(os.path.join(golden, args.config))
+    over = {}
+    if args.N:
+        over["N"] = args.N
+    if args.dt:
+        over["dt"] = args.dt
+    params = pkg.params_from_json(os.path.join(golden, args.config), **over)
     wp = pkg.scenarios.load_waypoints(os.path.join(golden, "lake_track_waypoints.csv"))
     B = args.batch
     want_traj = not args.no_traj
@@ -76,6 +84,8 @@ def main():
     batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_state, d_coef, d_ylo, d_yhi = t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"])
+    w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank) if args.weights_sweep else None
+    d_w = t(w_np) if w_np is not None else None
     mpc = pkg.BatchedMPC(params, B, device=local_rank)
     outs = mpc.alloc_outputs(B, dev, want_traj)
 
@@ -89,7 +99,7 @@ def main():
 
     def step():
         nonlocal gathered
-        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, outputs=outs)     # async on torch's current stream
+        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=outs)   # async on torch's current stream
         if dist is not None:
             gathered = pkg.sharding.gather_results(outs, B * world, dist)  # the path's only collective
 
@@ -102,7 +112,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, outputs=outs)
+        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=outs)
         ev[i][1].record()
         if dist is not None:
             gathered = pkg.sharding.gather_results(outs, B * world, dist)
@@ -129,12 +139,14 @@ def main():
     mean_iters = stats.iter_sum / max(1, stats.batch)
     stages = params.N - 1
     res = {
-        "metric": "MPC solves/sec (batch) at N=10 dt=0.1",
+        "metric": "MPC solves/sec (batch) at N=%d dt=%g" % (params.N, params.dt),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: %d lake-track states per GPU, 100 ms latency compensation, "
-                               "N=%d dt=%g, %s, trajectories %s" % (B, params.N, params.dt, args.config, "on" if want_traj else "off"),
+        "config": {"workload": "%s%d lake-track states per GPU, 100 ms latency compensation, N=%d dt=%g, %s, trajectories %s%s"
+                               % ("BASELINE.json configs[2]: " if (params.N == 10 and not args.weights_sweep and B == 65536) else "",
+                                  B, params.N, params.dt, args.config, "on" if want_traj else "off",
+                                  ", per-instance weight sweep" if args.weights_sweep else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
                    "parallelism": "%d independent shard(s), one all_gather of results" % world,
                    "branch_mode": "frozen", "tol": params.tol, "max_iter": params.max_iter},
@@ -142,14 +154,15 @@ def main():
         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
         "mean_iterations": mean_iters, "max_iterations": int(stats.iter_max),
     }
-    algo_bytes = (ALGO_BYTES_PER_SOLVE if want_traj else 176) * B
+    per_solve = 8 * (6 + 5 + 2) + 8 * 9 + (8 * 2 * params.N if want_traj else 0) + (8 * 12 if args.weights_sweep else 0)
+    algo_bytes = per_solve * B
     achieved_gbs = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            if pj.get("batch") == B and pj.get("config") == args.config:
+            if pj.get("batch") == B and pj.get("config") == args.config and params.N == 10 and not args.weights_sweep and want_traj:
                 traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -165,12 +178,15 @@ def main():
         # the checker, timed as the CPU baseline: oracle = plain-C restatement of the reference algorithm
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        cfg = O.load_config(args.config)
+        cfg = O.load_config(args.config, **over)
         n_done, worst_steer, worst_acc, t_cpu0 = 0, 0.0, 0.0, time.perf_counter()
         t_solve = 0.0
         while n_done < min(B, 4096) and (time.perf_counter() - t_cpu0) < args.cpu_seconds:
             i = n_done
             cfg.yaw_low, cfg.yaw_high = float(batch["yaw_lo"][i]), float(batch["yaw_hi"][i])
+            if w_np is not None:
+                for q in range(12):
+                    cfg.weights[q] = float(w_np[q, i])
             ts = time.perf_counter()
             st, o9, _, _, _ = O.mpc_solve(cfg, batch["state"][:, i], batch["coeffs"][:, i])
             t_solve += time.perf_counter() - ts

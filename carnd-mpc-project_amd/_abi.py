@@ -55,7 +55,7 @@ class MpcBatchStats(C.Structure):
 # every symbol include/mpc_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_params", "mpc_destroy",
            "mpc_last_error", "mpc_abi_version", "mpc_solve_batch_device", "mpc_solve_batch_host",
-           "mpc_synchronize", "mpc_get_stats"]
+           "mpc_synchronize", "mpc_get_stats", "mpc_debug_math"]
 
 _lib = None
 
@@ -95,6 +95,7 @@ def library():
     L.mpc_solve_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9
     L.mpc_synchronize.argtypes = [C.c_void_p]
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]
+    L.mpc_debug_math.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 4
     if L.mpc_abi_version() != ABI_VERSION:
         raise MpcError("ABI version mismatch between %s and the Python binding" % path)
     _lib = L

@@ -63,21 +63,21 @@ namespace mpc {
 /* ---- workspace layout ------------------------------------------------------ */
 /* A "field" is one double per instance.  Stage k (0..N-2) owns:
  *   two iterate slots: s_{k+1} (6), u_k (2), lam_{k+1} (6), bound duals of (psi_{k+1}, v_{k+1}, delta_k, a_k) (4+4)
- *   the Newton direction  ds_{k+1} (6), du_k (2), dlam_{k+1} (6)   -- stored in fp32
- *   the Riccati gains     K_k (2x6, fp32) and kff_k (2, fp64)      -- in LDS on the device when they fit
+ *   the Newton direction  ds_{k+1} (6), du_k (2), dlam_{k+1} (6)
+ *   the Riccati gains     K_k (2x6) and kff_k (2)   -- in LDS on the device when the launch allows it
  * Nothing else is kept: the stage model (sin/cos/atan, road polynomial, residual) is recomputed
  * in every sweep, because the kernel is limited by workspace traffic, not by arithmetic.
- * fp32 storage of direction and gains only makes the Newton step inexact at the 6e-8 level; all
- * residuals, the iterate, the multipliers and the convergence test stay fp64. */
+ * Everything is fp64: storing the direction or the gains in fp32 was tried and rejected -- an
+ * absolute error of ~1e-8 in a step component is fatal next to slacks of ~1e-9 at active bounds
+ * (+11 % iterations and a few non-converged instances on the 65 536-instance workload). */
 enum : int {
   F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
-  F_D = 2 * IT_SZ, D_N = 14, D_FIELDS = 7,                         /* 14 floats = 7 fields */
-  F_GK = F_D + D_FIELDS, GK_N = 12, GK_FIELDS = 6,                 /* 12 floats = 6 fields (HBM fallback) */
-  F_GF = F_GK + GK_FIELDS, GF_N = 2,                               /* 2 doubles              (HBM fallback) */
-  STAGE_SZ_LDS = F_GK,                                             /* 51 fields/stage with gains in LDS */
-  STAGE_SZ_GLOBAL = F_GF + GF_N,                                   /* 59 fields/stage with gains in HBM */
-  STAGE_SZ_HOST = 2 * IT_SZ + D_N + GK_N + GF_N                    /* 72: test-only host build, all fp64 slots */
+  F_D = 2 * IT_SZ, D_N = 14,                                       /* direction */
+  F_GK = F_D + D_N, GK_N = 12,                                     /* gains K (HBM placement) */
+  F_GF = F_GK + GK_N, GF_N = 2,                                    /* gains kff (HBM placement) */
+  STAGE_SZ_LDS = F_GK,                                             /* 58 fields/stage with gains in LDS */
+  STAGE_SZ_GLOBAL = F_GF + GF_N                                    /* 72 fields/stage with gains in HBM */
 };
 enum : int { D_S = 0, D_U = 6, D_LAM = 8 };                        /* direction entries */
 
@@ -85,64 +85,56 @@ MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
   return (int64_t)(N - 1) * (gains_in_lds ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL);
 }
 /* LDS bytes per wavefront for the gains of an N-step horizon */
-MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N * 4 + GF_N * 8) * 64; }
+MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N + GF_N) * 8 * 64; }
 
-/* Plain storage for the test-only host build: one instance, fields contiguous.  Direction and
- * gains are rounded through float on store so that the host build sees the device's numerics. */
+/* Plain storage for the test-only host build: one instance, fields contiguous. */
 struct HostWorkspace {
   double *base;
-  MPC_HD double &it(int k, int f) const { return base[k * STAGE_SZ_HOST + f]; }
-  MPC_HD double getD(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + j]; }
-  MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + j] = (double)(float)v; }
-  MPC_HD double getK(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + j]; }
-  MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + j] = (double)(float)v; }
-  MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + GK_N + j]; }
-  MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_HOST + 2 * IT_SZ + D_N + GK_N + j] = v; }
+  MPC_HD double &it(int k, int f) const { return base[k * STAGE_SZ_GLOBAL + f]; }
+  MPC_HD double getD(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_D + j]; }
+  MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_D + j] = v; }
+  MPC_HD double getK(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GK + j]; }
+  MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GK + j] = v; }
+  MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GF + j]; }
+  MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GF + j] = v; }
 };
 
 #if defined(__HIPCC__)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double gdouble;
-typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(3))) double ldouble;
-typedef __attribute__((address_space(3))) float lfloat;
 #else   /* host pass of hipcc: the kernel body is parsed but never run */
 typedef double gdouble;
-typedef float gfloat;
 typedef double ldouble;
-typedef float lfloat;
 #endif
 /* Device layout: the workspace is tiled per wavefront, [wave][stage*field][64 lanes].  One wave's
- * whole working set is ONE contiguous block (N=10, gains in LDS: 51 x 9 x 512 B = 230 KB; all 1024
- * waves of a 65536-instance launch: 235 MB, inside the 256 MB Infinity Cache): every access of a
- * wave is a single 512-byte (fp64) or 256-byte (fp32) line and consecutive fields are adjacent in
+ * whole working set is ONE contiguous block (N=10: 72 x 9 x 512 B = 324 KB, or 261 KB with the gains
+ * in LDS): every access of a wave is a single 512-byte line and consecutive fields are adjacent in
  * memory, which keeps DRAM pages and TLB entries local to the wave.  All pointers are typed into
  * their address space so that accesses are global_* / ds_* instructions, never flat_*. */
 template <bool GAINS_IN_LDS>
 struct TiledWorkspace {
   gdouble *tile;   /* this wave's tile */
-  lfloat *lk;      /* LDS: K, [stage][12][64] floats (when GAINS_IN_LDS) */
-  ldouble *lf;     /* LDS: kff, [stage][2][64] doubles */
+  ldouble *lg;     /* LDS: gains, [stage][14][64] doubles (when GAINS_IN_LDS) */
   int lane;
   static constexpr int STAGE = GAINS_IN_LDS ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL;
   MPC_HD gdouble &it(int k, int f) const { return tile[(k * STAGE + f) * 64 + lane]; }
-  MPC_HD gfloat *fptr(int k, int f0) const { return (gfloat *)(tile + (k * STAGE + f0) * 64); }
-  MPC_HD double getD(int k, int j) const { return (double)fptr(k, F_D)[j * 64 + lane]; }
-  MPC_HD void setD(int k, int j, double v) const { fptr(k, F_D)[j * 64 + lane] = (float)v; }
+  MPC_HD double getD(int k, int j) const { return tile[(k * STAGE + F_D + j) * 64 + lane]; }
+  MPC_HD void setD(int k, int j, double v) const { tile[(k * STAGE + F_D + j) * 64 + lane] = v; }
   MPC_HD double getK(int k, int j) const {
-    if (GAINS_IN_LDS) return (double)lk[(k * GK_N + j) * 64 + lane];
-    return (double)fptr(k, F_GK)[j * 64 + lane];
+    if (GAINS_IN_LDS) return lg[(k * (GK_N + GF_N) + j) * 64 + lane];
+    return tile[(k * STAGE + F_GK + j) * 64 + lane];
   }
   MPC_HD void setK(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lk[(k * GK_N + j) * 64 + lane] = (float)v;
-    else fptr(k, F_GK)[j * 64 + lane] = (float)v;
+    if (GAINS_IN_LDS) lg[(k * (GK_N + GF_N) + j) * 64 + lane] = v;
+    else tile[(k * STAGE + F_GK + j) * 64 + lane] = v;
   }
   MPC_HD double getF(int k, int j) const {
-    if (GAINS_IN_LDS) return lf[(k * GF_N + j) * 64 + lane];
+    if (GAINS_IN_LDS) return lg[(k * (GK_N + GF_N) + GK_N + j) * 64 + lane];
     return tile[(k * STAGE + F_GF + j) * 64 + lane];
   }
   MPC_HD void setF(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lf[(k * GF_N + j) * 64 + lane] = v;
+    if (GAINS_IN_LDS) lg[(k * (GK_N + GF_N) + GK_N + j) * 64 + lane] = v;
     else tile[(k * STAGE + F_GF + j) * 64 + lane] = v;
   }
 };
@@ -163,8 +155,6 @@ MPC_HD double frcp(double x) {
   return 1.0 / x;
 #endif
 }
-/* the value a float store would keep (direction entries are stored in fp32) */
-MPC_HD double f32r(double x) { return (double)(float)x; }
 /* x^p for the line-search switching heuristics only (thresholds, not results): single precision */
 MPC_HD double hpow(double x, double p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -543,9 +533,7 @@ struct Solver {
       const double n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
       ws.setD(k, D_S + 0, n0); ws.setD(k, D_S + 1, n1); ws.setD(k, D_S + 2, n2); ws.setD(k, D_S + 3, n3);
       ws.setD(k, D_S + 4, n4); ws.setD(k, D_S + 5, n5); ws.setD(k, D_U + 0, dd); ws.setD(k, D_U + 1, da);
-      /* what the trial point will actually add (the direction is stored in fp32): step limits and the
-       * directional derivative are taken on these values so that they are consistent with trial() */
-      const double q2 = f32r(n2), q3 = f32r(n3), q4 = f32r(n4), q5 = f32r(n5), qd = f32r(dd), qa = f32r(da);
+      const double q2 = n2, q3 = n3, q4 = n4, q5 = n5, qd = dd, qa = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
       const double xs[4] = {sn[2], sn[3], delta, acc};
       const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
@@ -562,7 +550,7 @@ struct Solver {
       }
       /* objective part of the directional derivative */
       double g = 2.0 * wc * sn[4] * q4 + 2.0 * we * sn[5] * q5 + 2.0 * wv * (sn[3] - vref) * q3 + 2.0 * wd * delta * qd;
-      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (qd - f32r(ddprev));
+      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (qd - ddprev);
       dphi += df * g;
       dxinf = fmax(dxinf, fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
                                fmax(fmax(fabs(n4), fabs(n5)), fmax(fabs(dd), fabs(da)))));

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -65,8 +66,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
   WS ws;
   ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
   ws.lane = threadIdx.x;
-  ws.lf = (mpc::ldouble *)smem;                                              /* kff: [stage][2][64] doubles */
-  ws.lk = (mpc::lfloat *)(smem + (int64_t)(P.N - 1) * mpc::GF_N * 64);       /* K:   [stage][12][64] floats */
+  ws.lg = (mpc::ldouble *)smem;                                              /* gains: [stage][14][64] doubles */
   mpc::Solver<WS> S(P, ws);
   int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
@@ -77,6 +77,14 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
            traj != nullptr);
   status[i] = s;
   if (iters) iters[i] = S.iters;
+}
+
+__global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  mpc::fsincos(x[i], &s, &c);
+  sn[i] = s; cs[i] = c; rc[i] = mpc::frcp(x[i]);
 }
 
 }  // namespace
@@ -134,9 +142,18 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   MpcHandle *h = new MpcHandle();
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  /* gains in LDS when four one-wave workgroups per CU (one per SIMD) still fit into 160 KB */
-  h->gains_in_lds = 4 * mpc::gains_lds_bytes_per_wave(p->N) <= kLdsPerCu;
-  h->lds_bytes = h->gains_in_lds ? (size_t)mpc::gains_lds_bytes_per_wave(p->N) : 0;
+  /* Launch shape.  Each workgroup is one wave.  LDS per workgroup both holds the Riccati gains (when
+   * they fit) and caps the number of resident waves per CU: fewer resident waves keep the combined
+   * working set (tile bytes x resident waves) inside the 256 MB Infinity Cache.  Defaults chosen from
+   * measurements; MPC_WAVES_PER_CU / MPC_GAINS_IN_LDS override them for experiments. */
+  int waves_per_cu = 2;
+  if (const char *e = getenv("MPC_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) waves_per_cu = v; }
+  /* LDS each workgroup claims: its share of the CU's 160 KB (this is what caps residency) */
+  h->lds_bytes = waves_per_cu > 4 ? 0 : (size_t)(kLdsPerCu / waves_per_cu / 256 * 256);
+  h->gains_in_lds = (size_t)mpc::gains_lds_bytes_per_wave(p->N) <= h->lds_bytes;
+  if (const char *e = getenv("MPC_GAINS_IN_LDS")) h->gains_in_lds = h->gains_in_lds && atoi(e) != 0;
+  (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+  (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, h->gains_in_lds) * 64;   /* doubles per wavefront tile */
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
@@ -193,7 +210,7 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
     hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), h->lds_bytes, s, h->params, B, ld, state, coeffs,
                        yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   else
-    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs,
+    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), h->lds_bytes, s, h->params, B, ld, state, coeffs,
                        yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
@@ -265,5 +282,26 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;
   }
+  return MPC_OK;
+}
+
+extern "C" int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc) {
+  if (n < 0 || (n > 0 && (!x || !sn || !cs || !rc))) return MPC_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_last_error = "no HIP device"; return MPC_ERR_NO_DEVICE; }
+  if (device >= 0) MPC_HIP_CHECK(hipSetDevice(device));
+  if (n == 0) return MPC_OK;
+  double *d = nullptr;
+  MPC_HIP_CHECK(hipMalloc((void **)&d, sizeof(double) * 4 * n));
+  hipError_t e = hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(mpc_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d, d + n, d + 2 * n, d + 3 * n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(sn, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cs, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(rc, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { g_last_error = std::string("mpc_debug_math: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
   return MPC_OK;
 }

@@ -154,6 +154,12 @@ int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
 
+/* ---- diagnostics ------------------------------------------------------------ */
+/* Evaluates the device's own light-weight math on n host values (the solver replaces libm's
+ * sincos and IEEE division by shorter sequences, see csrc/mpc_core.h): sn[i], cs[i] = sin/cos(x[i]),
+ * rc[i] = 1/x[i].  Used by the tests to bound their error on the real hardware. */
+int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc);
+
 #ifdef __cplusplus
 }
 #endif

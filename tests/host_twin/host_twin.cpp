@@ -19,7 +19,7 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
                                    int32_t *iters) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N;
-  std::vector<double> wsbuf((size_t)(N - 1) * mpc::STAGE_SZ_HOST);
+  std::vector<double> wsbuf((size_t)(N - 1) * mpc::STAGE_SZ_GLOBAL);
   for (int64_t i = 0; i < B; i++) {
     double st[6], cf[MPC_NCOEF], w[MPC_NW], o9[9];
     std::vector<double> tr(2 * N);
@@ -35,4 +35,8 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
     if (iters) iters[i] = it;
   }
   return MPC_OK;
+}
+
+extern "C" void mpc_host_twin_math(int64_t n, const double *x, double *sn, double *cs, double *rc) {
+  for (int64_t i = 0; i < n; i++) { mpc::fsincos(x[i], &sn[i], &cs[i]); rc[i] = mpc::frcp(x[i]); }
 }

@@ -224,3 +224,16 @@ def test_edge_cases_and_errors(pkg, golden_dir, torch_dev):
         mpc.set_params(q)
         r3 = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
         assert list(r3["status"][2:]) == [1, 1] and list(r3["iters"][2:]) == [3, 3]
+
+
+def test_device_light_math(pkg):
+    """The device's replacements for libm sincos and IEEE division (v_rcp_f64 + 2 Newton steps) on real hardware."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-4, 4, 50000), rng.uniform(-300, 300, 50000), rng.normal(0, 1e-3, 5000),
+                        10.0 ** rng.uniform(-12, 12, 20000) * rng.choice([-1.0, 1.0], 20000),
+                        np.array([np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7])])
+    sn = np.zeros_like(x); cs = np.zeros_like(x); rc = np.zeros_like(x)
+    from carnd_mpc_project_amd._abi import check
+    check(pkg.library().mpc_debug_math(0, len(x), x.ctypes.data, sn.ctypes.data, cs.ctypes.data, rc.ctypes.data), "mpc_debug_math")
+    assert np.max(np.abs(sn - np.sin(x))) < 4e-16 and np.max(np.abs(cs - np.cos(x))) < 4e-16
+    assert np.max(np.abs(rc * x - 1.0)) < 5e-16

@@ -100,3 +100,15 @@ def test_twin_edge_cases(pkg, host_twin, golden_dir):
     # empty batch
     e = {"state": np.zeros((6, 0)), "coeffs": np.zeros((5, 0)), "yaw_lo": np.zeros(0), "yaw_hi": np.zeros(0)}
     assert twin_solve(host_twin, params, e)["out"].shape == (9, 0)
+
+
+def test_twin_light_math(host_twin):
+    """fsincos (Cody-Waite + minimax kernels) against numpy over the argument ranges the model produces."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-4, 4, 20000), rng.uniform(-300, 300, 20000), rng.normal(0, 1e-3, 2000),
+                        np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7])])
+    sn = np.zeros_like(x); cs = np.zeros_like(x); rc = np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    host_twin.mpc_host_twin_math(C.c_int64(len(x)), p(x), p(sn), p(cs), p(rc))
+    assert np.max(np.abs(sn - np.sin(x))) < 4e-16 and np.max(np.abs(cs - np.cos(x))) < 4e-16
