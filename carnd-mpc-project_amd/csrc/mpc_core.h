@@ -102,9 +102,11 @@ struct HostWorkspace {
 #if defined(__HIPCC__)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(3))) double ldouble;
 #else   /* host pass of hipcc: the kernel body is parsed but never run */
 typedef double gdouble;
+typedef char gchar;
 typedef double ldouble;
 #endif
 /* Device layout: the workspace is tiled per wavefront, [wave][stage*field][64 lanes].  One wave's
@@ -117,25 +119,32 @@ struct TiledWorkspace {
   gdouble *tile;   /* this wave's tile */
   ldouble *lg;     /* LDS: gains, [stage][14][64] doubles (when GAINS_IN_LDS) */
   int lane;
-  static constexpr int STAGE = GAINS_IN_LDS ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL;
-  MPC_HD gdouble &it(int k, int f) const { return tile[(k * STAGE + f) * 64 + lane]; }
-  MPC_HD double getD(int k, int j) const { return tile[(k * STAGE + F_D + j) * 64 + lane]; }
-  MPC_HD void setD(int k, int j, double v) const { tile[(k * STAGE + F_D + j) * 64 + lane] = v; }
+  static constexpr unsigned STAGE = GAINS_IN_LDS ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL;
+  /* 32-bit unsigned element indices: the tile base is wave-uniform (SGPR pair), so each access is
+   * global_load/store v, v_offset, s[base] with one 32-bit add instead of 64-bit pointer math */
+  /* byte offsets are formed in 32 bits (a tile is < 4 GB) so that address = uniform base + zext(offset) */
+  MPC_HD gdouble &g(int k, int f) const {
+    return *(gdouble *)((gchar *)tile + (((unsigned)k * STAGE + (unsigned)f) * 64u + (unsigned)lane) * 8u);
+  }
+  MPC_HD unsigned li(int k, int j) const { return ((unsigned)k * (unsigned)(GK_N + GF_N) + (unsigned)j) * 64u + (unsigned)lane; }
+  MPC_HD gdouble &it(int k, int f) const { return g(k, f); }
+  MPC_HD double getD(int k, int j) const { return g(k, F_D + j); }
+  MPC_HD void setD(int k, int j, double v) const { g(k, F_D + j) = v; }
   MPC_HD double getK(int k, int j) const {
-    if (GAINS_IN_LDS) return lg[(k * (GK_N + GF_N) + j) * 64 + lane];
-    return tile[(k * STAGE + F_GK + j) * 64 + lane];
+    if (GAINS_IN_LDS) return lg[li(k, j)];
+    return g(k, F_GK + j);
   }
   MPC_HD void setK(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lg[(k * (GK_N + GF_N) + j) * 64 + lane] = v;
-    else tile[(k * STAGE + F_GK + j) * 64 + lane] = v;
+    if (GAINS_IN_LDS) lg[li(k, j)] = v;
+    else g(k, F_GK + j) = v;
   }
   MPC_HD double getF(int k, int j) const {
-    if (GAINS_IN_LDS) return lg[(k * (GK_N + GF_N) + GK_N + j) * 64 + lane];
-    return tile[(k * STAGE + F_GF + j) * 64 + lane];
+    if (GAINS_IN_LDS) return lg[li(k, GK_N + j)];
+    return g(k, F_GF + j);
   }
   MPC_HD void setF(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lg[(k * (GK_N + GF_N) + GK_N + j) * 64 + lane] = v;
-    else tile[(k * STAGE + F_GF + j) * 64 + lane] = v;
+    if (GAINS_IN_LDS) lg[li(k, GK_N + j)] = v;
+    else g(k, F_GF + j) = v;
   }
 };
 #endif
@@ -319,7 +328,11 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   MPC_HD bool backward(double dw) {
     const int I = it(cur);
-    double Pm[6][6], p[6], Pcc, pc; /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1 */
+    /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1; only the lower triangle of the symmetric
+     * matrices is ever written or read (PM/MX pick it), so the other half never occupies registers */
+    double Pm[6][6], p[6], Pcc, pc;
+#define PM(i, j) Pm[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
+#define MX(i, j) Mx[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
     MPC_UNROLL
     for (int i = 0; i < 6; i++) {
       p[i] = 0;
@@ -363,7 +376,7 @@ struct Solver {
       double t[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++)
-        t[i] = p[i] + Pm[i][0] * r0 + Pm[i][1] * r1 + Pm[i][2] * r2 + Pm[i][3] * r3 + Pm[i][4] * r4;
+        t[i] = p[i] + PM(i, 0) * r0 + PM(i, 1) * r1 + PM(i, 2) * r2 + PM(i, 3) * r3 + PM(i, 4) * r4;
       const double tc = pc + Pcc * rc;
       /* G^T applied to a (6-vector, c-scalar): outputs for inputs x,y,psi,v,e,delta,a */
 #define MPC_GT(w, wcs, o)                                                         \
@@ -391,7 +404,7 @@ struct Solver {
       const double Sgd = lsm ? 1.0 : df * 2.0 * wd + zld * isld + zud * isud, Sga = lsm ? 1.0 : zla * isla + zua * isua;
       double w5[6], w6[6];
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) { w5[i] = Bp * (Pm[i][2] + Pm[i][4]) + Pm[i][5]; w6[i] = dt * Pm[i][3]; }
+      for (int i = 0; i < 6; i++) { w5[i] = Bp * (PM(i, 2) + PM(i, 4)) + PM(i, 5); w6[i] = dt * PM(i, 3); }
       if (k == 0) {
         /* only the feed-forward of u_0 is needed (ds_0 = 0) */
         double o5[7], o6[7];
@@ -412,22 +425,22 @@ struct Solver {
       {
         double w[6], o[7];
         MPC_UNROLL
-        for (int i = 0; i < 6; i++) w[i] = Pm[i][0] + Aex * Pm[i][4];
+        for (int i = 0; i < 6; i++) w[i] = PM(i, 0) + Aex * PM(i, 4);
         MPC_GT(w, Pcc * Acx, o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][0] = o[i];
         MPC_UNROLL
-        for (int i = 0; i < 6; i++) w[i] = Pm[i][1];
+        for (int i = 0; i < 6; i++) w[i] = PM(i, 1);
         MPC_GT(w, -Pcc, o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][1] = o[i];
         MPC_UNROLL
-        for (int i = 0; i < 6; i++) w[i] = Axp * Pm[i][0] + Ayp * Pm[i][1] + Pm[i][2] + Pm[i][4];
+        for (int i = 0; i < 6; i++) w[i] = Axp * PM(i, 0) + Ayp * PM(i, 1) + PM(i, 2) + PM(i, 4);
         MPC_GT(w, 0.0, o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][2] = o[i];
         MPC_UNROLL
-        for (int i = 0; i < 6; i++) w[i] = Axv * Pm[i][0] + Ayv * Pm[i][1] + Apv * (Pm[i][2] + Pm[i][4]) + Pm[i][3];
+        for (int i = 0; i < 6; i++) w[i] = Axv * PM(i, 0) + Ayv * PM(i, 1) + Apv * (PM(i, 2) + PM(i, 4)) + PM(i, 3);
         MPC_GT(w, Pcc * Acv, o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][3] = o[i];
@@ -447,13 +460,13 @@ struct Solver {
       /* ---- add the Lagrangian Hessian of stage k: -lam_{k+1}^T d2F ---- */
       Mx[0][0] += -lc * fpp + le * h3;
       Mx[2][2] += (lx * cp + ly * sp) * vdt;
-      { const double h = (lx * sp - ly * cp) * dt; Mx[2][3] += h; Mx[3][2] += h; }
+      Mx[3][2] += (lx * sp - ly * cp) * dt;
       Mx[4][4] += lc * vdt * se;
-      { const double h = -lc * dt * ce; Mx[3][4] += h; Mx[4][3] += h; }
-      { const double h = -(lp + le) * dtLf; Mx[3][5] += h; Mx[5][3] += h; }
+      Mx[4][3] += -lc * dt * ce;
+      Mx[5][3] += -(lp + le) * dtLf;
       /* control terms */
       const double Rdd = Mx[5][5] + Hdd + Sgd + dw;
-      const double Rda = 0.5 * (Mx[5][6] + Mx[6][5]);
+      const double Rda = Mx[6][5];
       const double Raa = Mx[6][6] + Sga + dw;
       const double det = Rdd * Raa - Rda * Rda;
       if (!(Rdd > 0.0) || !(det > 0.0)) return false;
@@ -481,9 +494,9 @@ struct Solver {
       for (int i = 0; i < 6; i++) {
         MPC_UNROLL
         for (int j = 0; j <= i; j++) {
-          double q = (i < 5) ? 0.5 * (Mx[i][j] + Mx[j][i]) : ((j == 5) ? Hdd : 0.0);
+          double q = (i < 5) ? Mx[i][j] : ((j == 5) ? Hdd : 0.0);
           q += Sd[i] * Kd[j] + Sa[i] * Ka[j];
-          Pm[i][j] = q; Pm[j][i] = q;
+          Pm[i][j] = q;
         }
         p[i] = ((i < 5) ? qt[i] : -Hdd * ddl) + Sd[i] * kfd + Sa[i] * kfa;
       }
@@ -494,6 +507,8 @@ struct Solver {
       for (int i = 0; i < 6; i++) sn[i] = sk[i];
     }
 #undef MPC_GT
+#undef PM
+#undef MX
     return true;
   }
 

@@ -94,8 +94,8 @@ struct MpcHandle {
   int device = 0;
   int64_t max_batch = 0;
   int64_t ws_stride = 0;   /* doubles per wavefront tile of the workspace */
-  bool gains_in_lds = false;
-  size_t lds_bytes = 0;
+  int num_cus = 256;
+  int force_waves_per_cu = 0, force_gains_lds = -1;
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   double *ws = nullptr;
   hipStream_t stream = nullptr;
@@ -142,19 +142,21 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   MpcHandle *h = new MpcHandle();
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  /* Launch shape.  Each workgroup is one wave.  LDS per workgroup both holds the Riccati gains (when
-   * they fit) and caps the number of resident waves per CU: fewer resident waves keep the combined
-   * working set (tile bytes x resident waves) inside the 256 MB Infinity Cache.  Defaults chosen from
-   * measurements; MPC_WAVES_PER_CU / MPC_GAINS_IN_LDS override them for experiments. */
-  int waves_per_cu = 2;
-  if (const char *e = getenv("MPC_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) waves_per_cu = v; }
-  /* LDS each workgroup claims: its share of the CU's 160 KB (this is what caps residency) */
-  h->lds_bytes = waves_per_cu > 4 ? 0 : (size_t)(kLdsPerCu / waves_per_cu / 256 * 256);
-  h->gains_in_lds = (size_t)mpc::gains_lds_bytes_per_wave(p->N) <= h->lds_bytes;
-  if (const char *e = getenv("MPC_GAINS_IN_LDS")) h->gains_in_lds = h->gains_in_lds && atoi(e) != 0;
+  /* Launch shapes.  Each workgroup is one wave and the kernel needs all 512 registers, so at most one
+   * wave runs per SIMD (4 per CU).  Two variants, chosen per launch (measured):
+   *   small batches (<= 2 waves per CU): Riccati gains in LDS (14 doubles x stages x 64 lanes = 64.5 KB
+   *     at N=10; each workgroup claims half of the CU's 160 KB) -> lower latency per iteration;
+   *   larger batches: all four SIMDs of a CU busy, gains in the HBM tile.
+   * MPC_WAVES_PER_CU / MPC_GAINS_IN_LDS pin one variant for experiments. */
+  h->num_cus = prop.multiProcessorCount;
+  h->force_waves_per_cu = 0;
+  if (const char *e = getenv("MPC_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) h->force_waves_per_cu = v; }
+  h->force_gains_lds = -1;
+  if (const char *e = getenv("MPC_GAINS_IN_LDS")) h->force_gains_lds = atoi(e) != 0;
   (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
   (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-  h->ws_stride = mpc::workspace_fields_per_instance(p->N, h->gains_in_lds) * 64;   /* doubles per wavefront tile */
+  /* the workspace is sized for the larger of the two tile shapes */
+  h->ws_stride = mpc::workspace_fields_per_instance(p->N, false) * 64;   /* doubles per wavefront tile (HBM gains) */
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -206,12 +208,19 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  if (h->gains_in_lds)
-    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), h->lds_bytes, s, h->params, B, ld, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+  /* choose the launch shape for this batch */
+  const int64_t n_waves = (B + kBlock - 1) / kBlock;
+  int waves_per_cu = h->force_waves_per_cu ? h->force_waves_per_cu : (n_waves <= 2 * (int64_t)h->num_cus ? 2 : 4);
+  const size_t lds_bytes = waves_per_cu > 4 ? 0 : (size_t)(kLdsPerCu / waves_per_cu / 256 * 256);
+  bool gains_lds = (size_t)mpc::gains_lds_bytes_per_wave(h->params.N) <= lds_bytes;
+  if (h->force_gains_lds == 0) gains_lds = false;
+  const int64_t tile = mpc::workspace_fields_per_instance(h->params.N, gains_lds) * 64;
+  if (gains_lds)
+    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, s, h->params, B, ld, state, coeffs,
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, tile);
   else
-    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), h->lds_bytes, s, h->params, B, ld, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), waves_per_cu == 4 ? 0 : lds_bytes, s, h->params, B, ld,
+                       state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, tile);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
