@@ -87,6 +87,14 @@ MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
 /* LDS bytes per wavefront for the gains of an N-step horizon */
 MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N + GF_N) * 8 * 64; }
 
+/* Staging interface (see TiledWorkspace): a sweep asks for the record of the NEXT stage while it works
+ * on the current one.  stage_fetch_it copies the 22 fields of an iterate slot of stage k to staged
+ * positions 0..21 of buffer `buf`, stage_fetch_x copies 14 further fields (the direction, or the gains)
+ * to staged positions 22..35; sit()/sx() read them back; stage_wait<N>() waits until at most the N
+ * most recent copy instructions are still in flight.  On the host build all of this degenerates to
+ * direct reads. */
+enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
+
 /* Plain storage for the test-only host build: one instance, fields contiguous. */
 struct HostWorkspace {
   double *base;
@@ -97,6 +105,11 @@ struct HostWorkspace {
   MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GK + j] = v; }
   MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GF + j]; }
   MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GF + j] = v; }
+  MPC_HD void stage_fetch_it(int, int, int) const {}
+  MPC_HD void stage_fetch_x(int, int, int) const {}
+  template <int N> MPC_HD void stage_wait() const {}
+  MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
+  MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
 };
 
 #if defined(__HIPCC__)
@@ -104,48 +117,68 @@ struct HostWorkspace {
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) char lchar;
 #else   /* host pass of hipcc: the kernel body is parsed but never run */
 typedef double gdouble;
 typedef char gchar;
 typedef double ldouble;
+typedef char lchar;
 #endif
-/* Device layout: the workspace is tiled per wavefront, [wave][stage*field][64 lanes].  One wave's
- * whole working set is ONE contiguous block (N=10: 72 x 9 x 512 B = 324 KB, or 261 KB with the gains
- * in LDS): every access of a wave is a single 512-byte line and consecutive fields are adjacent in
- * memory, which keeps DRAM pages and TLB entries local to the wave.  All pointers are typed into
- * their address space so that accesses are global_* / ds_* instructions, never flat_*. */
-template <bool GAINS_IN_LDS>
+/* Device layout: the workspace is tiled per wavefront and, inside a tile, fields are interleaved in
+ * PAIRS per lane:  [wave][stage][field pair][64 lanes][2].  One wave's whole working set is one
+ * contiguous block (N=10: 72 x 9 x 512 B = 324 KB), and the two fields of a pair of one instance are 16
+ * contiguous bytes, so
+ *   - a pair moves with one 16-byte-per-lane access (global_load/store_dwordx4: the coalescing sweet spot),
+ *   - `global_load_lds_dwordx4` (LDS-DMA) moves each lane's OWN data, which keeps it correct under the
+ *     partial exec masks of a wave whose instances are in different solver phases.
+ * Each sweep double-buffers the next stage's record into LDS with LDS-DMA while it computes the current
+ * stage: the kernel needs all 512 registers (one wave per SIMD), so nothing else can hide the
+ * HBM / Infinity-Cache latency, and a register prefetch does not fit (it spilled 428 VGPRs).
+ * LDS: 2 buffers x 36 fields x 512 B = 36 KB per wave, 144 KB per CU at four waves.
+ * All pointers are typed into their address space: accesses are global_* / ds_* instructions, never flat_*;
+ * the tile base is wave-uniform and byte offsets are formed in 32 bits (saddr + voffset addressing). */
+template <bool STAGING>
 struct TiledWorkspace {
   gdouble *tile;   /* this wave's tile */
-  ldouble *lg;     /* LDS: gains, [stage][14][64] doubles (when GAINS_IN_LDS) */
+  ldouble *lbuf;   /* LDS staging area of this wave (STAGING) */
   int lane;
-  static constexpr unsigned STAGE = GAINS_IN_LDS ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL;
-  /* 32-bit unsigned element indices: the tile base is wave-uniform (SGPR pair), so each access is
-   * global_load/store v, v_offset, s[base] with one 32-bit add instead of 64-bit pointer math */
-  /* byte offsets are formed in 32 bits (a tile is < 4 GB) so that address = uniform base + zext(offset) */
+  static constexpr unsigned STAGE = STAGE_SZ_GLOBAL;
+  static constexpr unsigned PAIRS = STAGE_SZ_GLOBAL / 2;
   MPC_HD gdouble &g(int k, int f) const {
-    return *(gdouble *)((gchar *)tile + (((unsigned)k * STAGE + (unsigned)f) * 64u + (unsigned)lane) * 8u);
+    const unsigned e = (((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 64u + (unsigned)lane) * 2u + ((unsigned)f & 1u);
+    return *(gdouble *)((gchar *)tile + e * 8u);
   }
-  MPC_HD unsigned li(int k, int j) const { return ((unsigned)k * (unsigned)(GK_N + GF_N) + (unsigned)j) * 64u + (unsigned)lane; }
   MPC_HD gdouble &it(int k, int f) const { return g(k, f); }
   MPC_HD double getD(int k, int j) const { return g(k, F_D + j); }
   MPC_HD void setD(int k, int j, double v) const { g(k, F_D + j) = v; }
-  MPC_HD double getK(int k, int j) const {
-    if (GAINS_IN_LDS) return lg[li(k, j)];
-    return g(k, F_GK + j);
+  MPC_HD double getK(int k, int j) const { return g(k, F_GK + j); }
+  MPC_HD void setK(int k, int j, double v) const { g(k, F_GK + j) = v; }
+  MPC_HD double getF(int k, int j) const { return g(k, F_GF + j); }
+  MPC_HD void setF(int k, int j, double v) const { g(k, F_GF + j) = v; }
+  /* ---- staging ---- */
+  template <int NPAIRS>
+  MPC_HD void dma(int buf, int k, int f0, int dst_pair) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    MPC_UNROLL
+    for (int q = 0; q < NPAIRS; q++) {
+      const unsigned src = (((unsigned)k * PAIRS + ((unsigned)f0 >> 1) + (unsigned)q) * 64u + (unsigned)lane) * 16u;
+      const unsigned dst = (((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q) * 64u) * 16u;
+      __builtin_amdgcn_global_load_lds((gchar *)tile + src, (lchar *)lbuf + dst, 16, 0, 0);
+    }
+#endif
   }
-  MPC_HD void setK(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lg[li(k, j)] = v;
-    else g(k, F_GK + j) = v;
+  MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0); }
+  MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, F, STG_IT_OPS); }
+  template <int N> MPC_HD void stage_wait() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (STAGING) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
   }
-  MPC_HD double getF(int k, int j) const {
-    if (GAINS_IN_LDS) return lg[li(k, GK_N + j)];
-    return g(k, F_GF + j);
+  MPC_HD double sl(int buf, int j) const {
+    return lbuf[(((unsigned)buf * STG_SLOT_PAIRS + ((unsigned)j >> 1)) * 64u + (unsigned)lane) * 2u + ((unsigned)j & 1u)];
   }
-  MPC_HD void setF(int k, int j, double v) const {
-    if (GAINS_IN_LDS) lg[li(k, GK_N + j)] = v;
-    else g(k, F_GF + j) = v;
-  }
+  MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)g(k, I + j); }
+  MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)g(k, F + j); }
 };
 #endif
 
@@ -341,30 +374,53 @@ struct Solver {
     }
     const double rsc = lsm ? 0.0 : -1.0;             /* constraint right-hand side: -c, or 0 for the LS system */
     const double hxy = (lsm ? 1.0 : 0.0) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
+    /* Staging: record j of the iterate (the fields of stage j) sits in buffer (M-1-j)&1.  Stage k needs
+     * (u_k, lam_{k+1}, duals of u_k) from record k -- moved to registers one iteration earlier -- and
+     * (s_k, delta_{k-1}, duals of s_k) from record k-1; record k-2 is requested meanwhile. */
+    ws.template stage_wait<0>();                     /* earlier stores of this wave have landed */
+    ws.stage_fetch_it(0, M - 1, I);
+    ws.template stage_wait<0>();
     double sn[6];                                    /* s_{k+1} */
-    load_state(M, I, sn);
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
     {
-      const int ks = M - 1;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(sn[2], sn[3], sn[4], sn[5], ws.it(ks, I + F_ZL + 0), ws.it(ks, I + F_ZU + 0), ws.it(ks, I + F_ZL + 1),
-                  ws.it(ks, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      state_terms(sn[2], sn[3], sn[4], sn[5], ws.sit(0, M - 1, I, F_ZL + 0), ws.sit(0, M - 1, I, F_ZU + 0),
+                  ws.sit(0, M - 1, I, F_ZL + 1), ws.sit(0, M - 1, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       Pm[0][0] = hxy; Pm[1][1] = hxy; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
       Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
     }
+    /* inputs of stage k that live in record k, carried in registers */
+    double delta = ws.sit(0, M - 1, I, F_U + 0), acc = ws.sit(0, M - 1, I, F_U + 1);
+    double lx = ws.sit(0, M - 1, I, F_LAM + 0), ly = ws.sit(0, M - 1, I, F_LAM + 1), lp = ws.sit(0, M - 1, I, F_LAM + 2);
+    double lc = ws.sit(0, M - 1, I, F_LAM + 4), le = ws.sit(0, M - 1, I, F_LAM + 5);
+    double zld = ws.sit(0, M - 1, I, F_ZL + 2), zud = ws.sit(0, M - 1, I, F_ZU + 2);
+    double zla = ws.sit(0, M - 1, I, F_ZL + 3), zua = ws.sit(0, M - 1, I, F_ZU + 3);
+    if (M >= 2) ws.stage_fetch_it(1, M - 2, I);
     for (int k = M - 1; k >= 0; --k) {
-      /* ---- linearisation of stage k ---- */
+      /* ---- inputs of stage k ---- */
       double sk[6];
-      load_state(k, I, sk);
       double zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
+      double n_acc = 0, n_lx = 0, n_ly = 0, n_lp = 0, n_lc = 0, n_le = 0, n_zld = 0, n_zud = 0, n_zla = 0, n_zua = 0;
       if (k > 0) {
-        zlp = ws.it(k - 1, I + F_ZL + 0); zup = ws.it(k - 1, I + F_ZU + 0); zlv = ws.it(k - 1, I + F_ZL + 1); zuv = ws.it(k - 1, I + F_ZU + 1);
-        delprev = ws.it(k - 1, I + F_U + 0);
+        const int bk = (M - k) & 1;                  /* buffer of record k-1 */
+        if (k >= 2) { ws.stage_fetch_it(bk ^ 1, k - 2, I); ws.template stage_wait<STG_IT_OPS>(); }
+        else ws.template stage_wait<0>();
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) sk[i] = ws.sit(bk, k - 1, I, F_S + i);
+        zlp = ws.sit(bk, k - 1, I, F_ZL + 0); zup = ws.sit(bk, k - 1, I, F_ZU + 0);
+        zlv = ws.sit(bk, k - 1, I, F_ZL + 1); zuv = ws.sit(bk, k - 1, I, F_ZU + 1);
+        delprev = ws.sit(bk, k - 1, I, F_U + 0);
+        n_acc = ws.sit(bk, k - 1, I, F_U + 1);
+        n_lx = ws.sit(bk, k - 1, I, F_LAM + 0); n_ly = ws.sit(bk, k - 1, I, F_LAM + 1); n_lp = ws.sit(bk, k - 1, I, F_LAM + 2);
+        n_lc = ws.sit(bk, k - 1, I, F_LAM + 4); n_le = ws.sit(bk, k - 1, I, F_LAM + 5);
+        n_zld = ws.sit(bk, k - 1, I, F_ZL + 2); n_zud = ws.sit(bk, k - 1, I, F_ZU + 2);
+        n_zla = ws.sit(bk, k - 1, I, F_ZL + 3); n_zua = ws.sit(bk, k - 1, I, F_ZU + 3);
+      } else {
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) sk[i] = st[i];
       }
       const double v = sk[3];
-      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
-      const double lx = ws.it(k, I + F_LAM + 0), ly = ws.it(k, I + F_LAM + 1), lp = ws.it(k, I + F_LAM + 2);
-      const double lc = ws.it(k, I + F_LAM + 4), le = ws.it(k, I + F_LAM + 5);
-      const double zld = ws.it(k, I + F_ZL + 2), zud = ws.it(k, I + F_ZU + 2), zla = ws.it(k, I + F_ZL + 3), zua = ws.it(k, I + F_ZU + 3);
       Lin L;
       linearise(sk, delta, acc, sn, L);
       const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
@@ -505,6 +561,8 @@ struct Solver {
       Pcc = Hcc + dw; pc = gc;
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sn[i] = sk[i];
+      delta = delprev; acc = n_acc; lx = n_lx; ly = n_ly; lp = n_lp; lc = n_lc; le = n_le;
+      zld = n_zld; zud = n_zud; zla = n_zla; zua = n_zua;
     }
 #undef MPC_GT
 #undef PM
@@ -524,20 +582,30 @@ struct Solver {
     dphi = 0.0; dxinf = 0.0; xinf = 0.0;
     double sk[6];
     load_state(0, I, sk);
+    /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
+    ws.template stage_wait<0>();
+    ws.stage_fetch_it(0, 0, I);
+    ws.stage_fetch_x(0, 0, F_GK);
     for (int k = 0; k < M; ++k) {
+      const int bf = k & 1;
+      if (k + 1 < M) {
+        ws.stage_fetch_it(bf ^ 1, k + 1, I);
+        ws.stage_fetch_x(bf ^ 1, k + 1, F_GK);
+        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+      } else ws.template stage_wait<0>();
       double sn[6];
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) sn[i] = ws.it(k, I + F_S + i);
+      for (int i = 0; i < 6; i++) sn[i] = ws.sit(bf, k, I, F_S + i);
       const double v = sk[3];
-      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
+      const double delta = ws.sit(bf, k, I, F_U + 0), acc = ws.sit(bf, k, I, F_U + 1);
       Lin L;
       linearise(sk, delta, acc, sn, L);
-      double dd = ws.getF(k, 0), da = ws.getF(k, 1);
+      double dd = ws.sx(bf, k, F_GK, GK_N + 0), da = ws.sx(bf, k, F_GK, GK_N + 1);
       if (k > 0) {
-        dd += ws.getK(k, 0) * d0 + ws.getK(k, 1) * d1 + ws.getK(k, 2) * d2 + ws.getK(k, 3) * d3 + ws.getK(k, 4) * d5 +
-              ws.getK(k, 5) * ddprev;
-        da += ws.getK(k, 6) * d0 + ws.getK(k, 7) * d1 + ws.getK(k, 8) * d2 + ws.getK(k, 9) * d3 + ws.getK(k, 10) * d5 +
-              ws.getK(k, 11) * ddprev;
+        dd += ws.sx(bf, k, F_GK, 0) * d0 + ws.sx(bf, k, F_GK, 1) * d1 + ws.sx(bf, k, F_GK, 2) * d2 + ws.sx(bf, k, F_GK, 3) * d3 +
+              ws.sx(bf, k, F_GK, 4) * d5 + ws.sx(bf, k, F_GK, 5) * ddprev;
+        da += ws.sx(bf, k, F_GK, 6) * d0 + ws.sx(bf, k, F_GK, 7) * d1 + ws.sx(bf, k, F_GK, 8) * d2 + ws.sx(bf, k, F_GK, 9) * d3 +
+              ws.sx(bf, k, F_GK, 10) * d5 + ws.sx(bf, k, F_GK, 11) * ddprev;
       }
       const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const double n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
@@ -556,7 +624,7 @@ struct Solver {
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
         const double isl = frcp(xs[b] - lo[b]), isu = frcp(hi[b] - xs[b]);
-        const double zl = ws.it(k, I + F_ZL + b), zu = ws.it(k, I + F_ZU + b);
+        const double zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
         rmax = fmax(rmax, fmax(-dx[b] * isl, dx[b] * isu));
         const double dzl = mu * isl - zl - zl * isl * dx[b];
         const double dzu = mu * isu - zu + zu * isu * dx[b];
@@ -587,42 +655,60 @@ struct Solver {
     const int I = it(cur);
     const double hxy = (lsm ? 1.0 : 0.0) + dw;
     double L0, L1, L2, L3, L4, L5; /* lam+_{k+1}: x,y,psi,v,c,e */
+    /* staging: record j (iterate + direction of stage j) in buffer (M-1-j)&1; stage k uses record k-1
+     * directly and (delta_k, a_k, lam_{k+1}, d delta_k) of record k from registers */
+    ws.template stage_wait<0>();
+    ws.stage_fetch_it(0, M - 1, I);
+    ws.stage_fetch_x(0, M - 1, F_D);
+    ws.template stage_wait<0>();
     double sn[6];
-    load_state(M, I, sn);
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
+    double delta, acc, lx, ly, lp, lc, le, ddk;
     {
       const int ks = M - 1;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(sn[2], sn[3], sn[4], sn[5], ws.it(ks, I + F_ZL + 0), ws.it(ks, I + F_ZU + 0), ws.it(ks, I + F_ZL + 1),
-                  ws.it(ks, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      L0 = -(hxy * ws.getD(ks, D_S + 0));
-      L1 = -(hxy * ws.getD(ks, D_S + 1));
-      L2 = -(gp + (Hpp + dw) * ws.getD(ks, D_S + 2));
-      L3 = -(gv + (Hvv + dw) * ws.getD(ks, D_S + 3));
-      L4 = -(gc + (Hcc + dw) * ws.getD(ks, D_S + 4));
-      L5 = -(ge + (Hee + dw) * ws.getD(ks, D_S + 5));
-      ws.setD(ks, D_LAM + 0, L0 - ws.it(ks, I + F_LAM + 0)); ws.setD(ks, D_LAM + 1, L1 - ws.it(ks, I + F_LAM + 1));
-      ws.setD(ks, D_LAM + 2, L2 - ws.it(ks, I + F_LAM + 2)); ws.setD(ks, D_LAM + 3, L3 - ws.it(ks, I + F_LAM + 3));
-      ws.setD(ks, D_LAM + 4, L4 - ws.it(ks, I + F_LAM + 4)); ws.setD(ks, D_LAM + 5, L5 - ws.it(ks, I + F_LAM + 5));
+      state_terms(sn[2], sn[3], sn[4], sn[5], ws.sit(0, ks, I, F_ZL + 0), ws.sit(0, ks, I, F_ZU + 0), ws.sit(0, ks, I, F_ZL + 1),
+                  ws.sit(0, ks, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      L0 = -(hxy * ws.sx(0, ks, F_D, D_S + 0));
+      L1 = -(hxy * ws.sx(0, ks, F_D, D_S + 1));
+      L2 = -(gp + (Hpp + dw) * ws.sx(0, ks, F_D, D_S + 2));
+      L3 = -(gv + (Hvv + dw) * ws.sx(0, ks, F_D, D_S + 3));
+      L4 = -(gc + (Hcc + dw) * ws.sx(0, ks, F_D, D_S + 4));
+      L5 = -(ge + (Hee + dw) * ws.sx(0, ks, F_D, D_S + 5));
+      lx = ws.sit(0, ks, I, F_LAM + 0); ly = ws.sit(0, ks, I, F_LAM + 1); lp = ws.sit(0, ks, I, F_LAM + 2);
+      const double l3 = ws.sit(0, ks, I, F_LAM + 3);
+      lc = ws.sit(0, ks, I, F_LAM + 4); le = ws.sit(0, ks, I, F_LAM + 5);
+      ws.setD(ks, D_LAM + 0, L0 - lx); ws.setD(ks, D_LAM + 1, L1 - ly); ws.setD(ks, D_LAM + 2, L2 - lp);
+      ws.setD(ks, D_LAM + 3, L3 - l3); ws.setD(ks, D_LAM + 4, L4 - lc); ws.setD(ks, D_LAM + 5, L5 - le);
+      delta = ws.sit(0, ks, I, F_U + 0); acc = ws.sit(0, ks, I, F_U + 1);
+      ddk = ws.sx(0, ks, F_D, D_U + 0);
     }
+    if (M >= 2) { ws.stage_fetch_it(1, M - 2, I); ws.stage_fetch_x(1, M - 2, F_D); }
     for (int k = M - 1; k >= 1; --k) {
+      const int bk = (M - k) & 1;                    /* buffer of record k-1 */
+      if (k >= 2) {
+        ws.stage_fetch_it(bk ^ 1, k - 2, I);
+        ws.stage_fetch_x(bk ^ 1, k - 2, F_D);
+        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+      } else ws.template stage_wait<0>();
       double sk[6];
-      load_state(k, I, sk);
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sk[i] = ws.sit(bk, k - 1, I, F_S + i);
       const double v = sk[3];
-      const double delta = ws.it(k, I + F_U + 0), acc = ws.it(k, I + F_U + 1);
       Lin L;
       linearise(sk, delta, acc, sn, L);   /* the residual part is unused here and is eliminated */
       const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
-      const double lx = ws.it(k, I + F_LAM + 0), ly = ws.it(k, I + F_LAM + 1), lp = ws.it(k, I + F_LAM + 2);
-      const double lc = ws.it(k, I + F_LAM + 4), le = ws.it(k, I + F_LAM + 5);
-      const double dxk = ws.getD(k - 1, D_S + 0), dyk = ws.getD(k - 1, D_S + 1), dpk = ws.getD(k - 1, D_S + 2);
-      const double dvk = ws.getD(k - 1, D_S + 3), dck = ws.getD(k - 1, D_S + 4), dek = ws.getD(k - 1, D_S + 5);
-      const double ddk = ws.getD(k, D_U + 0);
-      const double lo0 = ws.it(k - 1, I + F_LAM + 0), lo1 = ws.it(k - 1, I + F_LAM + 1), lo2 = ws.it(k - 1, I + F_LAM + 2);
-      const double lo3 = ws.it(k - 1, I + F_LAM + 3), lo4 = ws.it(k - 1, I + F_LAM + 4), lo5 = ws.it(k - 1, I + F_LAM + 5);
+      const double dxk = ws.sx(bk, k - 1, F_D, D_S + 0), dyk = ws.sx(bk, k - 1, F_D, D_S + 1), dpk = ws.sx(bk, k - 1, F_D, D_S + 2);
+      const double dvk = ws.sx(bk, k - 1, F_D, D_S + 3), dck = ws.sx(bk, k - 1, F_D, D_S + 4), dek = ws.sx(bk, k - 1, F_D, D_S + 5);
+      const double lo0 = ws.sit(bk, k - 1, I, F_LAM + 0), lo1 = ws.sit(bk, k - 1, I, F_LAM + 1), lo2 = ws.sit(bk, k - 1, I, F_LAM + 2);
+      const double lo3 = ws.sit(bk, k - 1, I, F_LAM + 3), lo4 = ws.sit(bk, k - 1, I, F_LAM + 4), lo5 = ws.sit(bk, k - 1, I, F_LAM + 5);
+      const double n_delta = ws.sit(bk, k - 1, I, F_U + 0), n_acc = ws.sit(bk, k - 1, I, F_U + 1);
+      const double n_ddk = ws.sx(bk, k - 1, F_D, D_U + 0);
       const double vdt = v * dt, Apv = delta * dtLf;
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(sk[2], v, sk[4], sk[5], ws.it(k - 1, I + F_ZL + 0), ws.it(k - 1, I + F_ZU + 0), ws.it(k - 1, I + F_ZL + 1),
-                  ws.it(k - 1, I + F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      state_terms(sk[2], v, sk[4], sk[5], ws.sit(bk, k - 1, I, F_ZL + 0), ws.sit(bk, k - 1, I, F_ZU + 0),
+                  ws.sit(bk, k - 1, I, F_ZL + 1), ws.sit(bk, k - 1, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       /* curvature of stage k */
       const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
       const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
@@ -639,6 +725,7 @@ struct Solver {
       ws.setD(k - 1, D_LAM + 3, L3 - lo3); ws.setD(k - 1, D_LAM + 4, L4 - lo4); ws.setD(k - 1, D_LAM + 5, L5 - lo5);
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sn[i] = sk[i];
+      delta = n_delta; acc = n_acc; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5; ddk = n_ddk;
     }
   }
 
@@ -655,17 +742,27 @@ struct Solver {
     double zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0; /* zl_psi, zu_psi, zl_v, zu_v of s_k */
     double rdel_prev = 0, delprev = 0;
     const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
+    /* staging: stage k's iterate record and direction in buffer k&1, stage k+1 requested meanwhile */
+    ws.template stage_wait<0>();
+    ws.stage_fetch_it(0, 0, I);
+    ws.stage_fetch_x(0, 0, F_D);
     for (int k = 0; k < M; ++k) {
-      const double delo = ws.it(k, I + F_U + 0), acco = ws.it(k, I + F_U + 1);
-      const double ddel = ws.getD(k, D_U + 0), dacc = ws.getD(k, D_U + 1);
+      const int bf = k & 1;
+      if (k + 1 < M) {
+        ws.stage_fetch_it(bf ^ 1, k + 1, I);
+        ws.stage_fetch_x(bf ^ 1, k + 1, F_D);
+        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+      } else ws.template stage_wait<0>();
+      const double delo = ws.sit(bf, k, I, F_U + 0), acco = ws.sit(bf, k, I, F_U + 1);
+      const double ddel = ws.sx(bf, k, F_D, D_U + 0), dacc = ws.sx(bf, k, F_D, D_U + 1);
       const double delta = delo + alpha * ddel;
       const double acc = acco + alpha * dacc;
       double so[6], dso[6], sn[6], ln[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
-        so[i] = ws.it(k, I + F_S + i); dso[i] = ws.getD(k, D_S + i);
+        so[i] = ws.sit(bf, k, I, F_S + i); dso[i] = ws.sx(bf, k, F_D, D_S + i);
         sn[i] = so[i] + alpha * dso[i];
-        ln[i] = ws.it(k, I + F_LAM + i) + alpha * ws.getD(k, D_LAM + i);
+        ln[i] = ws.sit(bf, k, I, F_LAM + i) + alpha * ws.sx(bf, k, F_D, D_LAM + i);
       }
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
@@ -687,7 +784,7 @@ struct Solver {
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
         const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
-        const double zl = ws.it(k, I + F_ZL + b), zu = ws.it(k, I + F_ZU + b);
+        const double zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
         const double dzl = mu * islo - zl - zl * islo * dxb[b];
         const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
         const double sl = xn[b] - lo[b], su = hi[b] - xn[b];

@@ -35,12 +35,13 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
 
 /*
  * One instance per lane.  Inputs/outputs are [quantity][instance] so that a wave's access to one
- * quantity is a single contiguous 512-byte transaction; the workspace is tiled per wave
- * ([wave][stage*field][lane], see mpc_core.h).  GAINS_IN_LDS: the Riccati gains of all stages
- * live in the workgroup's LDS (4 KB per stage) instead of the HBM tile; chosen by the launcher when
- * four workgroups per CU still fit (one wave per SIMD).
+ * quantity is a single contiguous 512-byte transaction; the workspace is tiled per wave with fields
+ * interleaved in pairs per lane (see mpc_core.h).  STAGING: every sweep double-buffers the next
+ * stage's record into this workgroup's LDS with LDS-DMA (global_load_lds) while it computes.
  */
-template <bool GAINS_IN_LDS>
+constexpr size_t kStagingLdsBytes = 2u * mpc::STG_SLOT_PAIRS * 64u * 16u;   /* 36 KB per wave */
+
+template <bool STAGING>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const double *__restrict__ state,
     const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 #pragma unroll
     for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
   }
-  using WS = mpc::TiledWorkspace<GAINS_IN_LDS>;
+  using WS = mpc::TiledWorkspace<STAGING>;
   WS ws;
   ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
   ws.lane = threadIdx.x;
-  ws.lg = (mpc::ldouble *)smem;                                              /* gains: [stage][14][64] doubles */
+  ws.lbuf = (mpc::ldouble *)smem;
   mpc::Solver<WS> S(P, ws);
   int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
@@ -94,8 +95,7 @@ struct MpcHandle {
   int device = 0;
   int64_t max_batch = 0;
   int64_t ws_stride = 0;   /* doubles per wavefront tile of the workspace */
-  int num_cus = 256;
-  int force_waves_per_cu = 0, force_gains_lds = -1;
+  bool staging = true;
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   double *ws = nullptr;
   hipStream_t stream = nullptr;
@@ -142,21 +142,13 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   MpcHandle *h = new MpcHandle();
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  /* Launch shapes.  Each workgroup is one wave and the kernel needs all 512 registers, so at most one
-   * wave runs per SIMD (4 per CU).  Two variants, chosen per launch (measured):
-   *   small batches (<= 2 waves per CU): Riccati gains in LDS (14 doubles x stages x 64 lanes = 64.5 KB
-   *     at N=10; each workgroup claims half of the CU's 160 KB) -> lower latency per iteration;
-   *   larger batches: all four SIMDs of a CU busy, gains in the HBM tile.
-   * MPC_WAVES_PER_CU / MPC_GAINS_IN_LDS pin one variant for experiments. */
-  h->num_cus = prop.multiProcessorCount;
-  h->force_waves_per_cu = 0;
-  if (const char *e = getenv("MPC_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) h->force_waves_per_cu = v; }
-  h->force_gains_lds = -1;
-  if (const char *e = getenv("MPC_GAINS_IN_LDS")) h->force_gains_lds = atoi(e) != 0;
+  /* Launch shape: each workgroup is one wave; the kernel needs all 512 registers, so at most one wave runs
+   * per SIMD (4 per CU), and the 36 KB of staging LDS per wave fit four times into a CU's 160 KB.
+   * MPC_STAGING=0 selects the variant with ordinary loads (for A/B measurements). */
+  h->staging = true;
+  if (const char *e = getenv("MPC_STAGING")) h->staging = atoi(e) != 0;
   (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-  (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-  /* the workspace is sized for the larger of the two tile shapes */
-  h->ws_stride = mpc::workspace_fields_per_instance(p->N, false) * 64;   /* doubles per wavefront tile (HBM gains) */
+  h->ws_stride = mpc::workspace_fields_per_instance(p->N, false) * 64;   /* doubles per wavefront tile */
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -208,19 +200,12 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  /* choose the launch shape for this batch */
-  const int64_t n_waves = (B + kBlock - 1) / kBlock;
-  int waves_per_cu = h->force_waves_per_cu ? h->force_waves_per_cu : (n_waves <= 2 * (int64_t)h->num_cus ? 2 : 4);
-  const size_t lds_bytes = waves_per_cu > 4 ? 0 : (size_t)(kLdsPerCu / waves_per_cu / 256 * 256);
-  bool gains_lds = (size_t)mpc::gains_lds_bytes_per_wave(h->params.N) <= lds_bytes;
-  if (h->force_gains_lds == 0) gains_lds = false;
-  const int64_t tile = mpc::workspace_fields_per_instance(h->params.N, gains_lds) * 64;
-  if (gains_lds)
-    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, s, h->params, B, ld, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, tile);
+  if (h->staging)
+    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, state, coeffs,
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   else
-    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), waves_per_cu == 4 ? 0 : lds_bytes, s, h->params, B, ld,
-                       state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, tile);
+    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs,
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
