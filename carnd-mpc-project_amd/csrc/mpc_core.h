@@ -94,6 +94,9 @@ MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N
  * most recent copy instructions are still in flight.  On the host build all of this degenerates to
  * direct reads. */
 enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
+/* pair stores a stage issues in each sweep (all through store2): the counted waits let exactly these
+ * stay in flight besides the newest copy group */
+enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_COSTATE = 3, ST_TRIAL = IT_SZ / 2 };
 
 /* Plain storage for the test-only host build: one instance, fields contiguous. */
 struct HostWorkspace {
@@ -105,6 +108,7 @@ struct HostWorkspace {
   MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GK + j] = v; }
   MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GF + j]; }
   MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GF + j] = v; }
+  MPC_HD void store2(int k, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + f] = a; base[k * STAGE_SZ_GLOBAL + f + 1] = b; }
   MPC_HD void stage_fetch_it(int, int, int) const {}
   MPC_HD void stage_fetch_x(int, int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
@@ -149,6 +153,15 @@ struct TiledWorkspace {
     return *(gdouble *)((gchar *)tile + e * 8u);
   }
   MPC_HD gdouble &it(int k, int f) const { return g(k, f); }
+  /* both fields of a pair (f even) with ONE 16-byte store: the number of store instructions per stage is
+   * then exact, which the counted waits of the staged sweeps rely on */
+  MPC_HD void store2(int k, int f, double a, double b) const {
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    typedef __attribute__((address_space(1))) d2 gd2;
+    const unsigned e = (((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 64u + (unsigned)lane) * 16u;
+    d2 v; v.x = a; v.y = b;
+    *(gd2 *)((gchar *)tile + e) = v;
+  }
   MPC_HD double getD(int k, int j) const { return g(k, F_D + j); }
   MPC_HD void setD(int k, int j, double v) const { g(k, F_D + j) = v; }
   MPC_HD double getK(int k, int j) const { return g(k, F_GK + j); }
@@ -401,21 +414,19 @@ struct Solver {
       /* ---- inputs of stage k ---- */
       double sk[6];
       double zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
-      double n_acc = 0, n_lx = 0, n_ly = 0, n_lp = 0, n_lc = 0, n_le = 0, n_zld = 0, n_zud = 0, n_zla = 0, n_zua = 0;
+      const int bk = (M - k) & 1;                    /* buffer of record k-1 */
       if (k > 0) {
-        const int bk = (M - k) & 1;                  /* buffer of record k-1 */
-        if (k >= 2) { ws.stage_fetch_it(bk ^ 1, k - 2, I); ws.template stage_wait<STG_IT_OPS>(); }
-        else ws.template stage_wait<0>();
+        if (k >= 2) {
+          ws.stage_fetch_it(bk ^ 1, k - 2, I);
+          /* record k-1 must have landed; the gains stored by stage k+1 and the new request may stay in flight */
+          if (k == M - 1) ws.template stage_wait<STG_IT_OPS>();
+          else ws.template stage_wait<STG_IT_OPS + ST_BACKWARD>();
+        } else ws.template stage_wait<0>();
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = ws.sit(bk, k - 1, I, F_S + i);
         zlp = ws.sit(bk, k - 1, I, F_ZL + 0); zup = ws.sit(bk, k - 1, I, F_ZU + 0);
         zlv = ws.sit(bk, k - 1, I, F_ZL + 1); zuv = ws.sit(bk, k - 1, I, F_ZU + 1);
         delprev = ws.sit(bk, k - 1, I, F_U + 0);
-        n_acc = ws.sit(bk, k - 1, I, F_U + 1);
-        n_lx = ws.sit(bk, k - 1, I, F_LAM + 0); n_ly = ws.sit(bk, k - 1, I, F_LAM + 1); n_lp = ws.sit(bk, k - 1, I, F_LAM + 2);
-        n_lc = ws.sit(bk, k - 1, I, F_LAM + 4); n_le = ws.sit(bk, k - 1, I, F_LAM + 5);
-        n_zld = ws.sit(bk, k - 1, I, F_ZL + 2); n_zud = ws.sit(bk, k - 1, I, F_ZU + 2);
-        n_zla = ws.sit(bk, k - 1, I, F_ZL + 3); n_zua = ws.sit(bk, k - 1, I, F_ZU + 3);
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = st[i];
@@ -472,8 +483,7 @@ struct Solver {
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
         const double idet = frcp(det);
-        ws.setF(0, 0, -(Raa * rt_d - Rda * rt_a) * idet);
-        ws.setF(0, 1, -(-Rda * rt_d + Rdd * rt_a) * idet);
+        ws.store2(0, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -537,12 +547,11 @@ struct Solver {
       for (int j = 0; j < 6; j++) {
         Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
         Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
-        ws.setK(k, j, Kd[j]);
-        ws.setK(k, 6 + j, Ka[j]);
       }
       const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
-      ws.setF(k, 0, kfd);
-      ws.setF(k, 1, kfa);
+      MPC_UNROLL
+      for (int j = 0; j < 6; j += 2) { ws.store2(k, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
+      ws.store2(k, F_GF, kfd, kfa);
       /* ---- value function of stage k ---- */
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
@@ -561,8 +570,14 @@ struct Solver {
       Pcc = Hcc + dw; pc = gc;
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sn[i] = sk[i];
-      delta = delprev; acc = n_acc; lx = n_lx; ly = n_ly; lp = n_lp; lc = n_lc; le = n_le;
-      zld = n_zld; zud = n_zud; zla = n_zla; zua = n_zua;
+      /* inputs of stage k-1 that live in record k-1 (still staged in buffer bk): read them only now,
+       * so that they do not occupy registers during the stage algebra */
+      delta = delprev;
+      acc = ws.sit(bk, k - 1, I, F_U + 1);
+      lx = ws.sit(bk, k - 1, I, F_LAM + 0); ly = ws.sit(bk, k - 1, I, F_LAM + 1); lp = ws.sit(bk, k - 1, I, F_LAM + 2);
+      lc = ws.sit(bk, k - 1, I, F_LAM + 4); le = ws.sit(bk, k - 1, I, F_LAM + 5);
+      zld = ws.sit(bk, k - 1, I, F_ZL + 2); zud = ws.sit(bk, k - 1, I, F_ZU + 2);
+      zla = ws.sit(bk, k - 1, I, F_ZL + 3); zua = ws.sit(bk, k - 1, I, F_ZU + 3);
     }
 #undef MPC_GT
 #undef PM
@@ -591,7 +606,8 @@ struct Solver {
       if (k + 1 < M) {
         ws.stage_fetch_it(bf ^ 1, k + 1, I);
         ws.stage_fetch_x(bf ^ 1, k + 1, F_GK);
-        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        if (k == 0) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_FORWARD>();
       } else ws.template stage_wait<0>();
       double sn[6];
       MPC_UNROLL
@@ -614,8 +630,8 @@ struct Solver {
       const double n3 = d3 + dt * da - rsc * L.c[3];
       const double n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
       const double n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
-      ws.setD(k, D_S + 0, n0); ws.setD(k, D_S + 1, n1); ws.setD(k, D_S + 2, n2); ws.setD(k, D_S + 3, n3);
-      ws.setD(k, D_S + 4, n4); ws.setD(k, D_S + 5, n5); ws.setD(k, D_U + 0, dd); ws.setD(k, D_U + 1, da);
+      ws.store2(k, F_D + D_S + 0, n0, n1); ws.store2(k, F_D + D_S + 2, n2, n3);
+      ws.store2(k, F_D + D_S + 4, n4, n5); ws.store2(k, F_D + D_U + 0, dd, da);
       const double q2 = n2, q3 = n3, q4 = n4, q5 = n5, qd = dd, qa = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
       const double xs[4] = {sn[2], sn[3], delta, acc};
@@ -679,8 +695,8 @@ struct Solver {
       lx = ws.sit(0, ks, I, F_LAM + 0); ly = ws.sit(0, ks, I, F_LAM + 1); lp = ws.sit(0, ks, I, F_LAM + 2);
       const double l3 = ws.sit(0, ks, I, F_LAM + 3);
       lc = ws.sit(0, ks, I, F_LAM + 4); le = ws.sit(0, ks, I, F_LAM + 5);
-      ws.setD(ks, D_LAM + 0, L0 - lx); ws.setD(ks, D_LAM + 1, L1 - ly); ws.setD(ks, D_LAM + 2, L2 - lp);
-      ws.setD(ks, D_LAM + 3, L3 - l3); ws.setD(ks, D_LAM + 4, L4 - lc); ws.setD(ks, D_LAM + 5, L5 - le);
+      ws.store2(ks, F_D + D_LAM + 0, L0 - lx, L1 - ly); ws.store2(ks, F_D + D_LAM + 2, L2 - lp, L3 - l3);
+      ws.store2(ks, F_D + D_LAM + 4, L4 - lc, L5 - le);
       delta = ws.sit(0, ks, I, F_U + 0); acc = ws.sit(0, ks, I, F_U + 1);
       ddk = ws.sx(0, ks, F_D, D_U + 0);
     }
@@ -690,7 +706,8 @@ struct Solver {
       if (k >= 2) {
         ws.stage_fetch_it(bk ^ 1, k - 2, I);
         ws.stage_fetch_x(bk ^ 1, k - 2, F_D);
-        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        if (k == M - 1) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_COSTATE>();
       } else ws.template stage_wait<0>();
       double sk[6];
       MPC_UNROLL
@@ -721,8 +738,8 @@ struct Solver {
       const double n4 = -gc - (Hcc + dw) * dck;
       const double n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * dek - Hev * dvk;
       L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
-      ws.setD(k - 1, D_LAM + 0, L0 - lo0); ws.setD(k - 1, D_LAM + 1, L1 - lo1); ws.setD(k - 1, D_LAM + 2, L2 - lo2);
-      ws.setD(k - 1, D_LAM + 3, L3 - lo3); ws.setD(k - 1, D_LAM + 4, L4 - lo4); ws.setD(k - 1, D_LAM + 5, L5 - lo5);
+      ws.store2(k - 1, F_D + D_LAM + 0, L0 - lo0, L1 - lo1); ws.store2(k - 1, F_D + D_LAM + 2, L2 - lo2, L3 - lo3);
+      ws.store2(k - 1, F_D + D_LAM + 4, L4 - lo4, L5 - lo5);
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sn[i] = sk[i];
       delta = n_delta; acc = n_acc; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5; ddk = n_ddk;
@@ -751,7 +768,8 @@ struct Solver {
       if (k + 1 < M) {
         ws.stage_fetch_it(bf ^ 1, k + 1, I);
         ws.stage_fetch_x(bf ^ 1, k + 1, F_D);
-        ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        if (k == 0) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_TRIAL>();
       } else ws.template stage_wait<0>();
       const double delo = ws.sit(bf, k, I, F_U + 0), acco = ws.sit(bf, k, I, F_U + 1);
       const double ddel = ws.sx(bf, k, F_D, D_U + 0), dacc = ws.sx(bf, k, F_D, D_U + 1);
@@ -765,12 +783,12 @@ struct Solver {
         ln[i] = ws.sit(bf, k, I, F_LAM + i) + alpha * ws.sx(bf, k, F_D, D_LAM + i);
       }
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) {
-        ws.it(k, J + F_S + i) = sn[i];
-        ws.it(k, J + F_LAM + i) = ln[i];
-        R.lsum += fabs(ln[i]);
+      for (int i = 0; i < 6; i += 2) {
+        ws.store2(k, J + F_S + i, sn[i], sn[i + 1]);
+        ws.store2(k, J + F_LAM + i, ln[i], ln[i + 1]);
+        R.lsum += fabs(ln[i]) + fabs(ln[i + 1]);
       }
-      ws.it(k, J + F_U + 0) = delta; ws.it(k, J + F_U + 1) = acc;
+      ws.store2(k, J + F_U, delta, acc);
       Lin L;
       linearise(s, delta, acc, sn, L);
       MPC_UNROLL
@@ -795,12 +813,13 @@ struct Solver {
         a = fmax(fmin(a, ksm * isl), ksi * isl);
         c = fmax(fmin(c, ksm * isu), ksi * isu);
         zln[b] = a; zun[b] = c;
-        ws.it(k, J + F_ZL + b) = a; ws.it(k, J + F_ZU + b) = c;
         R.zsum += a + c;
         const double pl = sl * a, pu = su * c;
         R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
         prod *= sl * su;
       }
+      ws.store2(k, J + F_ZL + 0, zln[0], zln[1]); ws.store2(k, J + F_ZL + 2, zln[2], zln[3]);
+      ws.store2(k, J + F_ZU + 0, zun[0], zun[1]); ws.store2(k, J + F_ZU + 2, zun[2], zun[3]);
       R.L += log(prod);
       /* objective */
       const double dv = sn[3] - vref;
