@@ -242,11 +242,23 @@ MPC_HD void fsincos(double x, double *sn, double *cs) {
 
 /* IPOPT default constants (Waechter & Biegler 2006; IPOPT 3.12 option defaults) */
 struct IpmConst {
-  static constexpr double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, s_max = 100.0;
+#ifndef MPC_KAPPA_MU
+#define MPC_KAPPA_MU 0.2
+#endif
+#ifndef MPC_MU_INIT
+#define MPC_MU_INIT 0.1
+#endif
+#ifndef MPC_KAPPA_EPS
+#define MPC_KAPPA_EPS 10.0
+#endif
+#ifndef MPC_TAU_MIN
+#define MPC_TAU_MIN 0.99
+#endif
+  static constexpr double kappa_eps = MPC_KAPPA_EPS, kappa_mu = MPC_KAPPA_MU, theta_mu = 1.5, tau_min = MPC_TAU_MIN, s_max = 100.0;
   static constexpr double gamma_theta = 1e-5, gamma_phi = 1e-8, delta_sw = 1.0, s_theta = 1.1, s_phi = 2.3;
   static constexpr double eta_phi = 1e-8, gamma_alpha = 0.05, kappa_sigma = 1e10, kappa1 = 1e-2, kappa2 = 1e-2;
   static constexpr double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, kw_minus = 1.0 / 3.0, kw_plus = 8.0;
-  static constexpr double kw_plus_bar = 100.0, mu_init = 0.1, eps = 2.220446049250313e-16;
+  static constexpr double kw_plus_bar = 100.0, mu_init = MPC_MU_INIT, eps = 2.220446049250313e-16;
 };
 
 /* Vehicle::computeSpeedTarget, src/model/Vehicle.cpp:34-64 */
