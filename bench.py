@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--N", type=int, default=0, help="override Config::N (BASELINE.json configs[3]: 25)")
     ap.add_argument("--dt", type=float, default=0.0, help="override Config::dt (configs[3]: 0.05)")
     ap.add_argument("--weights-sweep", action="store_true", help="per-instance Config::weights (configs[4])")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-process path on a single GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -62,13 +65,18 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     golden = os.path.join(ROOT, "tests", "golden")
     over = {}
@@ -119,7 +127,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]

@@ -46,8 +46,16 @@ def gather_results(local, B, dist=None, group=None):
     R, b = packed.shape
     buf = torch.zeros((R, bmax), dtype=torch.float64, device=packed.device)
     buf[:, :b] = packed
-    gathered = [torch.empty_like(buf) for _ in range(ws)]
-    dist.all_gather(gathered, buf, group=group)
+    # RCCL ("nccl") gathers device tensors in place; gloo (CPU tests / single-GPU rehearsal) goes through the host
+    if dist.get_backend(group) != "nccl" and buf.is_cuda:
+        dev = buf.device
+        hbuf = buf.cpu()
+        hg = [torch.empty_like(hbuf) for _ in range(ws)]
+        dist.all_gather(hg, hbuf, group=group)
+        gathered = [g.to(dev) for g in hg]
+    else:
+        gathered = [torch.empty_like(buf) for _ in range(ws)]
+        dist.all_gather(gathered, buf, group=group)
     parts = []
     for r in range(ws):
         lo, hi = shard_bounds(B, ws, r)
