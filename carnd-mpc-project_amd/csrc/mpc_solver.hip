@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mpc_core.h"
+#include "mpc_run_core.h"
 
 namespace {
 
@@ -43,7 +44,7 @@ constexpr size_t kStagingLdsBytes = 2u * mpc::STG_SLOT_PAIRS * 64u * 16u;   /* 3
 
 template <bool STAGING>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
-    const MpcParams P, const int64_t B, const int64_t ld, const double *__restrict__ state,
+    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const double *__restrict__ state,
     const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
     const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
@@ -73,11 +74,46 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
   if (s == MPC_STATUS_SUCCESS) s = S.solve();
   double *o = out + i;
   double *t = traj ? traj + i : nullptr;
-  const int64_t l = ld;
+  const int64_t l = ldo;
   S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; },
            traj != nullptr);
   status[i] = s;
   if (iters) iters[i] = S.iters;
+}
+
+/* MPC::run pre-processing, one instance per lane (mpc_run_core.h).  rows of `pre`: state 0..5, coeffs 6..10,
+ * yaw_lo 11, yaw_hi 12, max_yaw_change 13, target_speed 14 */
+__global__ __launch_bounds__(256) void mpc_run_pre_kernel(const MpcParams P, int64_t B, int64_t ld, int npts,
+                                                          const double *__restrict__ pose, double *__restrict__ ptsx,
+                                                          double *__restrict__ ptsy, double *__restrict__ pre, int64_t ldp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double po[6], px[mpc::RUN_MAX_PTS], py[mpc::RUN_MAX_PTS];
+#pragma unroll
+  for (int q = 0; q < 6; q++) po[q] = pose[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < mpc::RUN_MAX_PTS; q++) { px[q] = q < npts ? ptsx[q * ld + i] : 0.0; py[q] = q < npts ? ptsy[q * ld + i] : 0.0; }
+  mpc::RunPre R;
+  mpc::run_pre(P, po, px, py, npts, R);
+#pragma unroll
+  for (int q = 0; q < mpc::RUN_MAX_PTS; q++) if (q < npts) { ptsx[q * ld + i] = px[q]; ptsy[q * ld + i] = py[q]; }
+#pragma unroll
+  for (int q = 0; q < 6; q++) pre[q * ldp + i] = R.state[q];
+#pragma unroll
+  for (int q = 0; q < 5; q++) pre[(6 + q) * ldp + i] = R.coef[q];
+  pre[11 * ldp + i] = R.yaw_lo; pre[12 * ldp + i] = R.yaw_hi; pre[13 * ldp + i] = R.max_yaw_change; pre[14 * ldp + i] = R.target_speed;
+}
+
+__global__ __launch_bounds__(256) void mpc_run_post_kernel(const MpcParams P, int64_t B, const double *__restrict__ pre, int64_t ldp,
+                                                           const double *__restrict__ out9, int64_t ld9, double *__restrict__ out8, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double r9[9], o8[8];
+#pragma unroll
+  for (int q = 0; q < 9; q++) r9[q] = out9[q * ld9 + i];
+  mpc::run_post(P, pre[13 * ldp + i], pre[14 * ldp + i], pre[3 * ldp + i], r9, o8);
+#pragma unroll
+  for (int q = 0; q < 8; q++) out8[q * ld + i] = o8[q];
 }
 
 __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc) {
@@ -103,6 +139,9 @@ struct MpcHandle {
   /* device staging for the host-pointer entry point and for statistics */
   double *d_in = nullptr;     /* state[6] coeffs[5] ylo yhi weights[12] = 25 rows */
   double *d_out = nullptr;    /* out[9] traj[2N] */
+  double *d_run = nullptr;    /* run(): pre[15] rows */
+  double *d_run9 = nullptr;   /* run(): solve()'s 9 rows, caller's leading dimension */
+  int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr;
   /* last call */
   int64_t last_B = 0;
@@ -179,6 +218,8 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_run) (void)hipFree(h->d_run);
+  if (h->d_run9) (void)hipFree(h->d_run9);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_iters) (void)hipFree(h->d_iters);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -187,12 +228,12 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   delete h;
 }
 
-extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *state,
-                                      const double *coeffs, const double *yaw_lo, const double *yaw_hi,
-                                      const double *weights, double *out, double *traj, int32_t *status,
-                                      int32_t *iters, void *stream_) {
+/* the launch; ld = leading dimension of the inputs, ldo = of out/traj */
+static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const double *state, const double *coeffs,
+                        const double *yaw_lo, const double *yaw_hi, const double *weights, double *out, double *traj,
+                        int32_t *status, int32_t *iters, void *stream_) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
-  if (B < 0 || ld < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || ldo < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
   h->last_B = B; h->last_status = status; h->last_iters = iters ? iters : h->d_iters; h->timed = false;
   if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
@@ -201,14 +242,53 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
   if (h->staging)
-    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, state, coeffs,
+    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, ldo, state, coeffs,
                        yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   else
-    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, state, coeffs,
+    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
                        yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
+  return MPC_OK;
+}
+
+extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                                      const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                      const double *weights, double *out, double *traj, int32_t *status,
+                                      int32_t *iters, void *stream_) {
+  return launch_solve(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
+}
+
+extern "C" int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
+                                    double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
+                                    double *pre, void *stream_) {
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
+  if (npts < 3 || npts > mpc::RUN_MAX_PTS) { g_last_error = "npts must be 3..8"; return MPC_ERR_INVALID; }
+  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (!pose || !ptsx || !ptsy || !out8 || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  MPC_HIP_CHECK(hipSetDevice(h->device));
+  const int64_t S = h->io_stride;
+  if (!h->d_run) MPC_HIP_CHECK(hipMalloc((void **)&h->d_run, sizeof(double) * 15 * S));
+  if (!h->d_run9 || h->run9_ld < ld) {       /* out9 scratch with the caller's leading dimension */
+    if (h->d_run9) MPC_HIP_CHECK(hipFree(h->d_run9));
+    h->d_run9 = nullptr;
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_run9, sizeof(double) * 9 * ld));
+    h->run9_ld = ld;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  double *d_pre = h->d_run;
+  const unsigned grid = (unsigned)((B + 255) / 256);
+  hipLaunchKernelGGL(mpc_run_pre_kernel, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, ptsx, ptsy, d_pre, S);
+  MPC_HIP_CHECK(hipGetLastError());
+  /* solve() writes its 9-vector where run()'s 8-vector goes afterwards: out9 rows 0..8 live in a scratch
+   * block with the caller's leading dimension only if it fits; otherwise in the handle's own block */
+  int rc = launch_solve(h, B, S, ld, d_pre, d_pre + 6 * S, d_pre + 11 * S, d_pre + 12 * S, nullptr, h->d_run9, traj, status, iters, stream_);
+  if (rc != MPC_OK) return rc;
+  hipLaunchKernelGGL(mpc_run_post_kernel, dim3(grid), dim3(256), 0, s, h->params, B, d_pre, S, h->d_run9, ld, out8, ld);
+  MPC_HIP_CHECK(hipGetLastError());
+  if (pre) MPC_HIP_CHECK(hipMemcpy2DAsync(pre, sizeof(double) * ld, d_pre, sizeof(double) * S, sizeof(double) * B, 15, hipMemcpyDeviceToDevice, s));
   return MPC_OK;
 }
 

@@ -138,7 +138,7 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     nwp = len(wp)
     g = _rng(seed, stream)
     lat = params.lookahead if latency_s is None else latency_s
-    keys = ("state", "coeffs", "yaw_lo", "yaw_hi", "ncoef", "max_yaw_change", "target_speed", "v0")
+    keys = ("state", "coeffs", "yaw_lo", "yaw_hi", "ncoef", "max_yaw_change", "target_speed", "v0", "pose", "ptsx", "ptsy")
     acc = {k: [] for k in keys}
     need = B
     while need > 0:
@@ -176,9 +176,14 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
         for kk in ("yaw_lo", "yaw_hi", "ncoef", "max_yaw_change", "target_speed"):
             acc[kk].append(pre[kk][take])
         acc["v0"].append(v[take])
+        # the raw telemetry MPC::run() receives: latency-compensated pose {x,y,psi,v,steering,acceleration}
+        # and the 6 global waypoints (struct-of-arrays, instance last)
+        acc["pose"].append(np.stack([px, py, psi, v, steer, accel])[:, take])
+        acc["ptsx"].append(wp[idx, 0].T[:, take]); acc["ptsy"].append(wp[idx, 1].T[:, take])
         need -= len(take)
-    out = {k: np.concatenate(acc[k], axis=1 if k in ("state", "coeffs") else 0) for k in keys}
-    for k in ("state", "coeffs"):
+    two_d = ("state", "coeffs", "pose", "ptsx", "ptsy")
+    out = {k: np.concatenate(acc[k], axis=1 if k in two_d else 0) for k in keys}
+    for k in two_d:
         out[k] = np.ascontiguousarray(out[k])
     return out
 

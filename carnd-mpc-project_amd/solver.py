@@ -83,6 +83,29 @@ class BatchedMPC:
             outputs["iters"].data_ptr(), C.c_void_p(s.cuda_stream)), "mpc_solve_batch_device")
         return outputs
 
+    def run_torch(self, pose, ptsx, ptsy, want_traj=False, want_pre=False, stream=None):
+        """MPC::run() for a batch on the device (src/control/MPC.cpp:327-382): pose [6,B] = x,y,psi,v,steering,
+        acceleration; ptsx/ptsy [npts,B] global waypoints, overwritten with the vehicle-frame waypoints as the
+        reference does.  Returns out8 [8,B] = {x1,y1,psi1,v1,steer in [-1,1],accel,cte1,epsi1} etc."""
+        import torch
+        B = pose.shape[1]
+        npts = ptsx.shape[0]
+        for name, t in (("pose", pose), ("ptsx", ptsx), ("ptsy", ptsy)):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape[1] != B:
+                raise ValueError("%s must be a contiguous float64 CUDA tensor [rows, B]" % name)
+        dev = pose.device
+        res = {"out8": torch.empty((8, B), dtype=torch.float64, device=dev),
+               "status": torch.empty((B,), dtype=torch.int32, device=dev),
+               "iters": torch.empty((B,), dtype=torch.int32, device=dev),
+               "traj": torch.empty((2 * self.N, B), dtype=torch.float64, device=dev) if want_traj else None,
+               "pre": torch.empty((15, B), dtype=torch.float64, device=dev) if want_pre else None}
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        check(library().mpc_run_batch_device(
+            self._h, B, B, int(npts), pose.data_ptr(), ptsx.data_ptr(), ptsy.data_ptr(), res["out8"].data_ptr(),
+            res["traj"].data_ptr() if want_traj else None, res["status"].data_ptr(), res["iters"].data_ptr(),
+            res["pre"].data_ptr() if want_pre else None, C.c_void_p(s.cuda_stream)), "mpc_run_batch_device")
+        return res
+
     # -- host path (numpy arrays; copies through PCIe) ------------------------
     def solve_numpy(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False):
         f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))

@@ -150,6 +150,20 @@ int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *stat
                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                          const double *weights, double *out, double *traj, int32_t *status,
                          int32_t *iters);
+/* ---- the caller of the path: MPC::run() for a batch -------------
+ * Pre-processing (waypoints to the vehicle frame, adaptive polynomial fit, cte0/epsi0, yaw bounds,
+ * speed tables: src/control/MPC.cpp:329-356), the solve, and the post-processing (steering adjustment,
+ * acceleration clamp, steering normalisation: MPC.cpp:360-381), all on the device:
+ *   pose [6][ld]      x, y, psi, v, steering, acceleration of the (latency-compensated) vehicle
+ *   ptsx, ptsy [npts][ld]  global waypoints in, VEHICLE-FRAME waypoints out (the reference transforms
+ *                     them in place, mpc_main.cpp:189-190 relies on it); 3 <= npts <= 8
+ *   out8 [8][ld]      {x1, y1, psi1, v1, steer in [-1,1], accel, cte1, epsi1} (MPC.cpp:381)
+ *   traj [2N][ld] or NULL, status [ld], iters [ld] or NULL   as in mpc_solve_batch_device
+ *   pre  [15][ld] or NULL  what run() handed to solve(): state[6], coeffs[5], yaw_lo, yaw_hi,
+ *                     max_yaw_change, target_speed (diagnostic) */
+int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
+                         double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
+                         double *pre, void *stream);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mpc_core.h"
+#include "mpc_run_core.h"
 
 extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, const double *state,
                                    const double *coeffs, const double *yaw_lo, const double *yaw_hi,
@@ -39,4 +40,27 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
 
 extern "C" void mpc_host_twin_math(int64_t n, const double *x, double *sn, double *cs, double *rc) {
   for (int64_t i = 0; i < n; i++) { mpc::fsincos(x[i], &sn[i], &cs[i]); rc[i] = mpc::frcp(x[i]); }
+}
+
+/* MPC::run pre/post-processing of the device header, one instance at a time (struct-of-arrays I/O like the ABI):
+ * pose[6][ld], pts[npts][ld] in/out, pre[15][ld] = state6 coeffs5 yaw_lo yaw_hi max_yaw_change target_speed */
+extern "C" int mpc_host_twin_run_pre(const MpcParams *p, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
+                                     double *ptsy, double *pre, int32_t *ncoef) {
+  if (npts < 3 || npts > mpc::RUN_MAX_PTS) return MPC_ERR_INVALID;
+  for (int64_t i = 0; i < B; i++) {
+    double po[6], px[mpc::RUN_MAX_PTS] = {0}, py[mpc::RUN_MAX_PTS] = {0};
+    for (int q = 0; q < 6; q++) po[q] = pose[q * ld + i];
+    for (int q = 0; q < npts; q++) { px[q] = ptsx[q * ld + i]; py[q] = ptsy[q * ld + i]; }
+    mpc::RunPre R;
+    mpc::run_pre(*p, po, px, py, npts, R);
+    for (int q = 0; q < npts; q++) { ptsx[q * ld + i] = px[q]; ptsy[q * ld + i] = py[q]; }
+    for (int q = 0; q < 6; q++) pre[q * ld + i] = R.state[q];
+    for (int q = 0; q < 5; q++) pre[(6 + q) * ld + i] = R.coef[q];
+    pre[11 * ld + i] = R.yaw_lo; pre[12 * ld + i] = R.yaw_hi; pre[13 * ld + i] = R.max_yaw_change; pre[14 * ld + i] = R.target_speed;
+    if (ncoef) ncoef[i] = R.ncoef;
+  }
+  return MPC_OK;
+}
+extern "C" void mpc_host_twin_run_post(const MpcParams *p, double max_yaw_change, double target_speed, double v0, const double *r9, double *o8) {
+  mpc::run_post(*p, max_yaw_change, target_speed, v0, r9, o8);
 }

@@ -1,0 +1,102 @@
+"""MPC::run() pre/post-processing: the device implementation
+(carnd-mpc-project_amd/csrc/mpc_run_core.h) against the oracle's restatement of MPC.cpp:327-382 and against the
+vectorised numpy generator.  CPU tests use the TEST-ONLY host build of the same header; the gpu test goes through
+mpc_run_batch_device."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import TEST_CPP, TOL_ACCEL, TOL_STEER, TOL_TRAJ, vp
+
+
+def _oracle_run(cfgname, tel, i):
+    cfg = O.load_config(cfgname)
+    pose = tel["pose"][:, i]
+    st, out8, tx, ty, pre, info = O.mpc_run(cfg, pose, tel["ptsx"][:, i], tel["ptsy"][:, i])
+    return st, out8, pre
+
+
+@pytest.mark.parametrize("cfgname", ["config-fast.json", "config-stable.json"])
+def test_run_pre_host_build_matches_oracle_and_numpy(pkg, host_twin, golden_dir, waypoints, cfgname):
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    B = 256
+    tel = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=51)
+    pose = np.ascontiguousarray(tel["pose"]); px = tel["ptsx"].copy(); py = tel["ptsy"].copy()
+    pre = np.zeros((15, B)); nc = np.zeros(B, dtype=np.int32)
+    rc = host_twin.mpc_host_twin_run_pre(C.byref(params), C.c_int64(B), C.c_int64(B), 6, vp(pose), vp(px), vp(py), vp(pre), vp(nc))
+    assert rc == 0
+    # against the numpy generator (same formulas, LAPACK QR)
+    assert np.array_equal(nc, tel["ncoef"])
+    assert np.max(np.abs(pre[:6] - tel["state"])) < 1e-9
+    assert np.max(np.abs(pre[6:11] - tel["coeffs"]) / np.maximum(1e-3, np.abs(tel["coeffs"]))) < 1e-6
+    assert np.max(np.abs(pre[11] - tel["yaw_lo"])) < 1e-9 and np.max(np.abs(pre[12] - tel["yaw_hi"])) < 1e-9
+    assert np.max(np.abs(pre[14] - tel["target_speed"])) < 1e-12
+    # against the oracle (Householder QR restated from utils.cpp)
+    cfg = O.load_config(cfgname)
+    for i in range(0, B, 8):
+        opre, opx, opy = O.run_pre(cfg, tel["pose"][:, i], tel["ptsx"][:, i], tel["ptsy"][:, i])
+        assert opre.nc == nc[i]
+        assert np.max(np.abs(px[:, i] - opx)) < 1e-11 and np.max(np.abs(py[:, i] - opy)) < 1e-11   # in place, vehicle frame
+        assert np.max(np.abs(pre[:6, i] - np.array(list(opre.state)))) < 1e-9
+        assert np.max(np.abs(pre[6:11, i] - np.array(list(opre.coef)[:5]))) < 1e-9
+        assert abs(pre[11, i] - opre.yaw_low) < 1e-9 and abs(pre[12, i] - opre.yaw_high) < 1e-9
+        assert abs(pre[13, i] - opre.max_yaw_change) < 1e-9 and abs(pre[14, i] - opre.target_speed) < 1e-12
+
+
+def test_run_pre_known_answer_and_post(pkg, host_twin, golden_dir):
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    pose = np.array(TEST_CPP["pose"]).reshape(6, 1).copy()
+    px = np.array(TEST_CPP["ptsx"]).reshape(6, 1).copy(); py = np.array(TEST_CPP["ptsy"]).reshape(6, 1).copy()
+    pre = np.zeros((15, 1)); nc = np.zeros(1, dtype=np.int32)
+    host_twin.mpc_host_twin_run_pre(C.byref(params), C.c_int64(1), C.c_int64(1), 6, vp(pose), vp(px), vp(py), vp(pre), vp(nc))
+    assert nc[0] == 3
+    assert pre[6:9, 0] == pytest.approx([-0.176556100493, -0.0259923242089, 0.00302916583378], abs=1e-12)
+    assert pre[12, 0] == pytest.approx(0.484345392317, abs=1e-11) and pre[11, 0] == -0.1
+    # post-processing against the oracle on synthetic results, incl. the steering adjustment and both clamps
+    cfg = O.load_config("config-stable.json")
+    rng = np.random.default_rng(7)
+    host_twin.mpc_host_twin_run_post.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    for _ in range(200):
+        r9 = rng.normal(size=9); r9[6] = rng.uniform(-0.6, 0.6); r9[7] = rng.uniform(-9, 5)
+        myc = rng.uniform(-1.2, 1.2); tgt = rng.uniform(5, 50); v0 = rng.uniform(0, 55)
+        o8 = np.zeros(8)
+        host_twin.mpc_host_twin_run_post(C.byref(params), myc, tgt, v0, vp(r9), vp(o8))
+        opre = O.OrcRunPre(); opre.max_yaw_change = myc; opre.target_speed = tgt
+        ref = O.run_post(cfg, opre, v0, r9)
+        assert np.array_equal(o8, ref)
+
+
+@pytest.mark.gpu
+def test_run_batch_device_matches_oracle(pkg, golden_dir, waypoints):
+    import torch
+    cfgname = "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    B = 4096
+    tel = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=52)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pose, px, py = t(tel["pose"]), t(tel["ptsx"]), t(tel["ptsy"])
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.run_torch(pose, px, py, want_traj=True, want_pre=True)
+        torch.cuda.synchronize()
+        out8 = r["out8"].cpu().numpy(); pre = r["pre"].cpu().numpy(); status = r["status"].cpu().numpy()
+        traj = r["traj"].cpu().numpy()
+        # the same instances through the solve-only entry point, fed with the numpy preprocessing
+        rs = mpc.solve_torch(t(tel["state"]), t(tel["coeffs"]), t(tel["yaw_lo"]), t(tel["yaw_hi"]))
+        torch.cuda.synchronize()
+        out9 = rs["out"].cpu().numpy()
+    assert (status == 0).all()
+    assert np.max(np.abs(pre[:6] - tel["state"])) < 1e-9 and np.max(np.abs(pre[11] - tel["yaw_lo"])) < 1e-9
+    assert np.max(np.abs(out8[:4] - out9[:4])) < 1e-6 and np.max(np.abs(out8[6:8] - out9[4:6])) < 1e-6
+    assert np.max(np.abs(traj[1] - out8[0])) == 0
+    vpx = px.cpu().numpy()
+    assert np.all(np.diff(vpx, axis=0) > 0)          # waypoints came back in the vehicle frame (monotone x by construction)
+    for i in range(0, B, 64):
+        st, ref8, opre = _oracle_run(cfgname, tel, i)
+        assert st == 0
+        assert abs(out8[4, i] - ref8[4]) * params.max_steering < TOL_STEER
+        assert abs(out8[5, i] - ref8[5]) < TOL_ACCEL
+        assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
