@@ -55,7 +55,8 @@ class MpcBatchStats(C.Structure):
 # every symbol include/mpc_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_params", "mpc_destroy",
            "mpc_last_error", "mpc_abi_version", "mpc_solve_batch_device", "mpc_solve_batch_host",
-           "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device"]
+           "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
+           "mpc_telemetry_batch_device"]
 
 _lib = None
 
@@ -97,6 +98,8 @@ def library():
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]
     L.mpc_debug_math.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 4
     L.mpc_run_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
+    L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
+                                             [C.c_void_p])
     if L.mpc_abi_version() != ABI_VERSION:
         raise MpcError("ABI version mismatch between %s and the Python binding" % path)
     _lib = L

@@ -164,5 +164,42 @@ MPC_HD void run_post(const MpcParams &P, double max_yaw_change, double target_sp
   o8[0] = r9[0]; o8[1] = r9[1]; o8[2] = r9[2]; o8[3] = r9[3]; o8[4] = sv; o8[5] = accel; o8[6] = r9[4]; o8[7] = r9[5];
 }
 
+/* ---- N2: the telemetry handler around run(), src/mpc_main.cpp:126-159 and :171-174 ------------------ */
+/* tel = {x, y, psi (rad, any range), speed (mph), steering_angle (simulator sign), previous throttle command};
+ * extra = the handler's mean solve time added to Config::lookahead (mpc_main.cpp:158).
+ * -> pose {x,y,psi,v,steering,acceleration} after latency compensation (Vehicle::update + Vehicle::move) */
+MPC_HD void telemetry_to_pose(const MpcParams &P, const double *tel, double extra, double *pose) {
+  double psi = tel[2];
+  while (psi >= M_PI) psi -= 2.0 * M_PI;                 /* normalizeAngle, mpc_main.cpp:127 */
+  while (psi < -M_PI) psi += 2.0 * M_PI;
+  const double v = tel[3] * 1609.34 / 3600.0;            /* MpH2MpS, :129 */
+  const double steer = -tel[4];                          /* :131 */
+  const double acc = (tel[5] - v / 50.0) * 6.0;          /* :156 */
+  pose[0] = tel[0]; pose[1] = tel[1]; pose[2] = psi; pose[3] = v; pose[4] = steer; pose[5] = acc;
+  if (P.latency_ms != 0) {                               /* :157-159, Vehicle::move (Vehicle.cpp:145-168) */
+    const double dtm = P.lookahead + extra;
+    const double dist = v * dtm;
+    double sn, cs;
+    fsincos(psi, &sn, &cs);
+    pose[0] = tel[0] + dist * cs;
+    pose[1] = tel[1] + dist * sn;
+    pose[2] = psi + steer * dist / P.Lf;                 /* Vehicle::length = Config::Lf, mpc_main.cpp:155 */
+    pose[3] = v + acc * dtm;                             /* not clamped: Vehicle.cpp:156 is overwritten at :167 */
+  }
+}
+/* Vehicle::computeThrottle (Vehicle.cpp:81-103) */
+MPC_HD double compute_throttle(const MpcParams &P, double accel, double target) {
+  const double keep = target / P.max_speed;
+  if (accel >= 0.0) return accel < 0.001 ? keep : fmin(1.0, keep + (1.0 - keep) * accel / P.max_acceleration);
+  if (accel <= -15.0) return -1.0;
+  const double base = accel < -10.0 ? 0.95 : (accel < -5.0 ? 0.9 : 0.85);
+  return -base - (1.0 - base) * accel / P.max_deceleration;
+}
+/* mpc_main.cpp:171-174: run()'s result -> the command sent back to the simulator */
+MPC_HD void command_from_run(const MpcParams &P, const double *o8, double *steer_cmd, double *throttle_cmd) {
+  *steer_cmd = -o8[4];
+  *throttle_cmd = compute_throttle(P, o8[5], o8[3]);
+}
+
 }  // namespace mpc
 #endif

@@ -83,14 +83,21 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 
 /* MPC::run pre-processing, one instance per lane (mpc_run_core.h).  rows of `pre`: state 0..5, coeffs 6..10,
  * yaw_lo 11, yaw_hi 12, max_yaw_change 13, target_speed 14 */
+template <bool TELEMETRY>
 __global__ __launch_bounds__(256) void mpc_run_pre_kernel(const MpcParams P, int64_t B, int64_t ld, int npts,
-                                                          const double *__restrict__ pose, double *__restrict__ ptsx,
+                                                          const double *__restrict__ pose, double extra, double *__restrict__ ptsx,
                                                           double *__restrict__ ptsy, double *__restrict__ pre, int64_t ldp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   double po[6], px[mpc::RUN_MAX_PTS], py[mpc::RUN_MAX_PTS];
 #pragma unroll
   for (int q = 0; q < 6; q++) po[q] = pose[q * ld + i];
+  if (TELEMETRY) {   /* rows are the simulator's telemetry: latency compensation first (mpc_main.cpp:126-159) */
+    double t6[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) t6[q] = po[q];
+    mpc::telemetry_to_pose(P, t6, extra, po);
+  }
 #pragma unroll
   for (int q = 0; q < mpc::RUN_MAX_PTS; q++) { px[q] = q < npts ? ptsx[q * ld + i] : 0.0; py[q] = q < npts ? ptsy[q * ld + i] : 0.0; }
   mpc::RunPre R;
@@ -105,15 +112,23 @@ __global__ __launch_bounds__(256) void mpc_run_pre_kernel(const MpcParams P, int
 }
 
 __global__ __launch_bounds__(256) void mpc_run_post_kernel(const MpcParams P, int64_t B, const double *__restrict__ pre, int64_t ldp,
-                                                           const double *__restrict__ out9, int64_t ld9, double *__restrict__ out8, int64_t ld) {
+                                                           const double *__restrict__ out9, int64_t ld9, double *__restrict__ out8,
+                                                           double *__restrict__ cmd, int64_t ld) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   double r9[9], o8[8];
 #pragma unroll
   for (int q = 0; q < 9; q++) r9[q] = out9[q * ld9 + i];
   mpc::run_post(P, pre[13 * ldp + i], pre[14 * ldp + i], pre[3 * ldp + i], r9, o8);
+  if (out8) {
 #pragma unroll
-  for (int q = 0; q < 8; q++) out8[q * ld + i] = o8[q];
+    for (int q = 0; q < 8; q++) out8[q * ld + i] = o8[q];
+  }
+  if (cmd) {         /* the reply of the telemetry handler (mpc_main.cpp:171-174) */
+    double sc, tc;
+    mpc::command_from_run(P, o8, &sc, &tc);
+    cmd[i] = sc; cmd[ld + i] = tc;
+  }
 }
 
 __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc) {
@@ -260,18 +275,19 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
   return launch_solve(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
 }
 
-extern "C" int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
-                                    double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
-                                    double *pre, void *stream_) {
+/* run() for a batch; `tel` selects the telemetry rows as input (with latency compensation) and `cmd` the reply */
+static int run_impl(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, bool tel, double extra, double *ptsx,
+                    double *ptsy, double *out8, double *cmd, double *traj, int32_t *status, int32_t *iters, double *pre,
+                    void *stream_) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
   if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
   if (npts < 3 || npts > mpc::RUN_MAX_PTS) { g_last_error = "npts must be 3..8"; return MPC_ERR_INVALID; }
   if (B == 0) { h->last_B = 0; return MPC_OK; }
-  if (!pose || !ptsx || !ptsy || !out8 || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  if (!pose || !ptsx || !ptsy || !(out8 || cmd) || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   MPC_HIP_CHECK(hipSetDevice(h->device));
   const int64_t S = h->io_stride;
   if (!h->d_run) MPC_HIP_CHECK(hipMalloc((void **)&h->d_run, sizeof(double) * 15 * S));
-  if (!h->d_run9 || h->run9_ld < ld) {       /* out9 scratch with the caller's leading dimension */
+  if (!h->d_run9 || h->run9_ld < ld) {       /* solve()'s 9 rows, with the caller's leading dimension (traj shares it) */
     if (h->d_run9) MPC_HIP_CHECK(hipFree(h->d_run9));
     h->d_run9 = nullptr;
     MPC_HIP_CHECK(hipMalloc((void **)&h->d_run9, sizeof(double) * 9 * ld));
@@ -280,16 +296,28 @@ extern "C" int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npt
   hipStream_t s = (hipStream_t)stream_;
   double *d_pre = h->d_run;
   const unsigned grid = (unsigned)((B + 255) / 256);
-  hipLaunchKernelGGL(mpc_run_pre_kernel, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, ptsx, ptsy, d_pre, S);
+  if (tel) hipLaunchKernelGGL(mpc_run_pre_kernel<true>, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, extra, ptsx, ptsy, d_pre, S);
+  else hipLaunchKernelGGL(mpc_run_pre_kernel<false>, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, 0.0, ptsx, ptsy, d_pre, S);
   MPC_HIP_CHECK(hipGetLastError());
-  /* solve() writes its 9-vector where run()'s 8-vector goes afterwards: out9 rows 0..8 live in a scratch
-   * block with the caller's leading dimension only if it fits; otherwise in the handle's own block */
   int rc = launch_solve(h, B, S, ld, d_pre, d_pre + 6 * S, d_pre + 11 * S, d_pre + 12 * S, nullptr, h->d_run9, traj, status, iters, stream_);
   if (rc != MPC_OK) return rc;
-  hipLaunchKernelGGL(mpc_run_post_kernel, dim3(grid), dim3(256), 0, s, h->params, B, d_pre, S, h->d_run9, ld, out8, ld);
+  hipLaunchKernelGGL(mpc_run_post_kernel, dim3(grid), dim3(256), 0, s, h->params, B, d_pre, S, h->d_run9, ld, out8, cmd, ld);
   MPC_HIP_CHECK(hipGetLastError());
   if (pre) MPC_HIP_CHECK(hipMemcpy2DAsync(pre, sizeof(double) * ld, d_pre, sizeof(double) * S, sizeof(double) * B, 15, hipMemcpyDeviceToDevice, s));
   return MPC_OK;
+}
+
+extern "C" int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
+                                    double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
+                                    double *pre, void *stream_) {
+  if (h && B > 0 && !out8) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  return run_impl(h, B, ld, npts, pose, false, 0.0, ptsx, ptsy, out8, nullptr, traj, status, iters, pre, stream_);
+}
+
+extern "C" int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
+                                          double *ptsx, double *ptsy, double *cmd, double *out8, int32_t *status, void *stream_) {
+  if (h && B > 0 && !cmd) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  return run_impl(h, B, ld, npts, tel, true, extra_latency, ptsx, ptsy, out8, cmd, nullptr, status, nullptr, nullptr, stream_);
 }
 
 extern "C" int mpc_synchronize(MpcHandle *h) {

@@ -106,6 +106,27 @@ class BatchedMPC:
             res["pre"].data_ptr() if want_pre else None, C.c_void_p(s.cuda_stream)), "mpc_run_batch_device")
         return res
 
+    def telemetry_torch(self, tel, ptsx, ptsy, extra_latency=0.0, want_out8=False, stream=None):
+        """The telemetry handler around run() (src/mpc_main.cpp:126-174) for a batch: tel [6,B] = x, y, psi,
+        speed [mph], steering_angle (simulator sign), previous throttle.  Returns cmd [2,B] = (steering_angle,
+        throttle) of the reply, status, and optionally run()'s 8-vector."""
+        import torch
+        B = tel.shape[1]
+        npts = ptsx.shape[0]
+        for name, t in (("tel", tel), ("ptsx", ptsx), ("ptsy", ptsy)):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape[1] != B:
+                raise ValueError("%s must be a contiguous float64 CUDA tensor [rows, B]" % name)
+        dev = tel.device
+        res = {"cmd": torch.empty((2, B), dtype=torch.float64, device=dev),
+               "status": torch.empty((B,), dtype=torch.int32, device=dev),
+               "out8": torch.empty((8, B), dtype=torch.float64, device=dev) if want_out8 else None}
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        check(library().mpc_telemetry_batch_device(
+            self._h, B, B, int(npts), tel.data_ptr(), float(extra_latency), ptsx.data_ptr(), ptsy.data_ptr(),
+            res["cmd"].data_ptr(), res["out8"].data_ptr() if want_out8 else None, res["status"].data_ptr(),
+            C.c_void_p(s.cuda_stream)), "mpc_telemetry_batch_device")
+        return res
+
     # -- host path (numpy arrays; copies through PCIe) ------------------------
     def solve_numpy(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False):
         f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))

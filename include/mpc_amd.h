@@ -164,6 +164,14 @@ int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *stat
 int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
                          double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
                          double *pre, void *stream);
+/* The telemetry handler around run() (src/mpc_main.cpp:126-159, 171-174):
+ *   tel [6][ld]   x, y, psi [rad], speed [mph], steering_angle (simulator sign), previous throttle command
+ *   extra_latency seconds added to Config::lookahead (the handler's mean solve time, mpc_main.cpp:158)
+ *   ptsx, ptsy    as in mpc_run_batch_device (in: global, out: vehicle frame)
+ *   cmd [2][ld]   steering_angle and throttle of the reply (mpc_main.cpp:183-184)
+ *   out8 [8][ld] or NULL   run()'s own return vector */
+int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
+                               double *ptsx, double *ptsy, double *cmd, double *out8, int32_t *status, void *stream);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);

@@ -64,3 +64,11 @@ extern "C" int mpc_host_twin_run_pre(const MpcParams *p, int64_t B, int64_t ld, 
 extern "C" void mpc_host_twin_run_post(const MpcParams *p, double max_yaw_change, double target_speed, double v0, const double *r9, double *o8) {
   mpc::run_post(*p, max_yaw_change, target_speed, v0, r9, o8);
 }
+
+/* N2: telemetry handler pieces (mpc_run_core.h) */
+extern "C" void mpc_host_twin_tel_pose(const MpcParams *p, const double *tel6, double extra, double *pose6) {
+  mpc::telemetry_to_pose(*p, tel6, extra, pose6);
+}
+extern "C" void mpc_host_twin_tel_cmd(const MpcParams *p, const double *o8, double *cmd2) {
+  mpc::command_from_run(*p, o8, &cmd2[0], &cmd2[1]);
+}

@@ -204,3 +204,27 @@ def kkt_certificate(cfg, state, coef, vars_, active_tol=1e-6):
     tot = lib().orc_kkt_certificate(C.byref(cfg), dptr(state), dptr(coef), len(coef), dptr(vars_),
                                     active_tol, C.byref(s), C.byref(p), C.byref(b))
     return tot, s.value, p.value, b.value
+
+
+def vehicle_move(cfg, pose, dt):
+    """Vehicle::move (Vehicle.cpp:145-168) on pose = {x,y,psi,v,steering,acceleration}."""
+    p = arr(pose).copy()
+    lib().orc_vehicle_move(C.byref(cfg), dptr(p), float(dt))
+    return p
+
+
+def compute_throttle(cfg, accel, target):
+    return lib().orc_compute_throttle(C.byref(cfg), float(accel), float(target), cfg.max_acceleration, cfg.max_deceleration)
+
+
+def telemetry_handler(cfg, tel6, ptsx, ptsy, extra=0.0, opt=None):
+    """The onMessage handler around run(), src/mpc_main.cpp:126-174: tel6 = x, y, psi, speed[mph], steering_angle,
+    previous throttle command -> (status, steer_value, throttle_value, out8)."""
+    x, y, psi, mph, sa, thr = [float(t) for t in tel6]
+    psi = lib().orc_normalize_angle(psi)
+    v = mph * 1609.34 / 3600.0
+    pose = np.array([x, y, psi, v, -sa, (thr - v / 50.0) * 6.0])
+    if cfg.latency:
+        pose = vehicle_move(cfg, pose, cfg.lookahead + extra)
+    st, out8, tx, ty, pre, info = mpc_run(cfg, pose, ptsx, ptsy, opt)
+    return st, -out8[4], compute_throttle(cfg, out8[5], out8[3]), out8

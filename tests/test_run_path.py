@@ -100,3 +100,83 @@ def test_run_batch_device_matches_oracle(pkg, golden_dir, waypoints):
         assert abs(out8[4, i] - ref8[4]) * params.max_steering < TOL_STEER
         assert abs(out8[5, i] - ref8[5]) < TOL_ACCEL
         assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
+
+
+# ---- N2: the telemetry handler around run() (src/mpc_main.cpp:126-174) ----------------------------------------------
+def _telemetry_from_pose(pose, rng):
+    """Simulator-side telemetry whose handler-side pose is `pose` before latency compensation."""
+    B = pose.shape[1]
+    tel = np.empty((6, B))
+    tel[0], tel[1] = pose[0], pose[1]
+    tel[2] = pose[2] + 2 * np.pi * rng.integers(-1, 2, size=B)      # the simulator reports psi in [0, 2 pi)
+    tel[3] = pose[3] * 3600.0 / 1609.34
+    tel[4] = -pose[4]
+    tel[5] = pose[5] / 6.0 + pose[3] / 50.0
+    return tel
+
+
+def test_telemetry_pieces_host_build_match_oracle(pkg, host_twin, golden_dir):
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    cfg = O.load_config("config-fast.json")
+    rng = np.random.default_rng(11)
+    host_twin.mpc_host_twin_tel_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    host_twin.mpc_host_twin_tel_cmd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    for _ in range(300):
+        tel = np.array([rng.uniform(-200, 200), rng.uniform(-200, 200), rng.uniform(-7, 7), rng.uniform(0, 110),
+                        rng.uniform(-0.44, 0.44), rng.uniform(-1, 1)])
+        extra = rng.uniform(0, 0.05)
+        pose = np.zeros(6)
+        host_twin.mpc_host_twin_tel_pose(C.byref(params), vp(tel), extra, vp(pose))
+        v = tel[3] * 1609.34 / 3600.0
+        ref = np.array([tel[0], tel[1], O.lib().orc_normalize_angle(tel[2]), v, -tel[4], (tel[5] - v / 50.0) * 6.0])
+        if cfg.latency:
+            ref = O.vehicle_move(cfg, ref, cfg.lookahead + extra)
+        assert np.max(np.abs(pose - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+        assert pose[4] == -tel[4]      # psi is NOT re-normalised after move(), as in the reference
+        o8 = rng.normal(size=8); o8[3] = rng.uniform(0, 50); o8[5] = rng.choice([0.0, 5e-4, *rng.uniform(-20, 6, size=3)])
+        cmd = np.zeros(2)
+        host_twin.mpc_host_twin_tel_cmd(C.byref(params), vp(o8), vp(cmd))
+        assert cmd[0] == -o8[4]
+        assert cmd[1] == O.compute_throttle(cfg, o8[5], o8[3])
+    # every branch of computeThrottle (Vehicle.cpp:81-103)
+    for acc in (0.0, 0.0005, 1.0, 100.0, -1.0, -5.0, -7.0, -10.0, -12.0, -15.0, -30.0):
+        o8 = np.zeros(8); o8[3] = 20.0; o8[5] = acc; cmd = np.zeros(2)
+        host_twin.mpc_host_twin_tel_cmd(C.byref(params), vp(o8), vp(cmd))
+        assert cmd[1] == O.compute_throttle(cfg, acc, 20.0)
+
+
+@pytest.mark.gpu
+def test_telemetry_batch_device_matches_oracle_handler(pkg, golden_dir, waypoints):
+    import torch
+    cfgname = "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    cfg = O.load_config(cfgname)
+    B = 2048
+    sc = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=53)
+    rng = np.random.default_rng(5)
+    tel = _telemetry_from_pose(sc["pose"], rng)
+    extra = 0.004
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.telemetry_torch(t(tel), t(sc["ptsx"]), t(sc["ptsy"]), extra_latency=extra, want_out8=True)
+        torch.cuda.synchronize()
+        cmd = r["cmd"].cpu().numpy(); st = r["status"].cpu().numpy(); out8 = r["out8"].cpu().numpy()
+        # cmd-only call (out8 = NULL) gives the same reply
+        r2 = mpc.telemetry_torch(t(tel), t(sc["ptsx"]), t(sc["ptsy"]), extra_latency=extra)
+        torch.cuda.synchronize()
+        assert torch.equal(r2["cmd"], r["cmd"])
+    assert np.array_equal(cmd[0], -out8[4])
+    checked = 0
+    for i in range(0, B, 32):
+        ost, osteer, othr, o8 = O.telemetry_handler(cfg, tel[:, i], sc["ptsx"][:, i], sc["ptsy"][:, i], extra)
+        assert ost == st[i] or (ost != 0 and st[i] != 0)
+        if ost != 0:
+            continue
+        checked += 1
+        assert abs(cmd[0, i] - osteer) * params.max_steering < TOL_STEER
+        # throttle is piecewise in accel: compare away from its breakpoints
+        if min(abs(o8[5] - b) for b in (0.0, 0.001, -5.0, -10.0, -15.0)) > 1e-4:
+            assert abs(cmd[1, i] - othr) < 1e-5
+        assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - o8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
+    assert checked >= 48
