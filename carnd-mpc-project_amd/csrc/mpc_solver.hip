@@ -131,6 +131,20 @@ __global__ __launch_bounds__(256) void mpc_run_post_kernel(const MpcParams P, in
   }
 }
 
+/* rollout bookkeeping: next state <- solve()'s step-1 rows; worst status and summed iterations per instance */
+__global__ __launch_bounds__(256) void mpc_rollout_step_kernel(int64_t B, int64_t ld, int first, const double *__restrict__ out9,
+                                                               double *__restrict__ state, const int32_t *__restrict__ st_step,
+                                                               const int32_t *__restrict__ it_step, int32_t *__restrict__ status,
+                                                               int32_t *__restrict__ iters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+#pragma unroll
+  for (int q = 0; q < 6; q++) state[q * ld + i] = out9[q * ld + i];
+  const int32_t s = st_step[i];
+  status[i] = first ? s : (s > status[i] ? s : status[i]);
+  if (iters) iters[i] = (first ? 0 : iters[i]) + it_step[i];
+}
+
 __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -157,7 +171,7 @@ struct MpcHandle {
   double *d_run = nullptr;    /* run(): pre[15] rows */
   double *d_run9 = nullptr;   /* run(): solve()'s 9 rows, caller's leading dimension */
   int64_t run9_ld = 0;
-  int32_t *d_status = nullptr, *d_iters = nullptr;
+  int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr;
   /* last call */
   int64_t last_B = 0;
   const int32_t *last_status = nullptr, *last_iters = nullptr;
@@ -237,6 +251,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_run9) (void)hipFree(h->d_run9);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_iters) (void)hipFree(h->d_iters);
+  if (h->d_rstat) (void)hipFree(h->d_rstat);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -318,6 +333,35 @@ extern "C" int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, i
                                           double *ptsx, double *ptsy, double *cmd, double *out8, int32_t *status, void *stream_) {
   if (h && B > 0 && !cmd) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   return run_impl(h, B, ld, npts, tel, true, extra_latency, ptsx, ptsy, out8, cmd, nullptr, status, nullptr, nullptr, stream_);
+}
+
+extern "C" int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int steps, double *state, const double *coeffs,
+                                        const double *yaw_lo, const double *yaw_hi, const double *weights, double *hist,
+                                        int32_t *status, int32_t *iters, void *stream_) {
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
+  if (steps < 1) { g_last_error = "steps < 1"; return MPC_ERR_INVALID; }
+  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (!state || !coeffs || !yaw_lo || !yaw_hi || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  MPC_HIP_CHECK(hipSetDevice(h->device));
+  if (!hist && (!h->d_run9 || h->run9_ld < ld)) {
+    if (h->d_run9) MPC_HIP_CHECK(hipFree(h->d_run9));
+    h->d_run9 = nullptr;
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_run9, sizeof(double) * 9 * ld));
+    h->run9_ld = ld;
+  }
+  if (!h->d_rstat) MPC_HIP_CHECK(hipMalloc((void **)&h->d_rstat, sizeof(int32_t) * h->io_stride));
+  hipStream_t s = (hipStream_t)stream_;
+  const unsigned grid = (unsigned)((B + 255) / 256);
+  for (int t = 0; t < steps; t++) {
+    double *o9 = hist ? hist + (int64_t)t * 9 * ld : h->d_run9;
+    int rc = launch_solve(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, o9, nullptr, h->d_rstat, h->d_iters, stream_);
+    if (rc != MPC_OK) return rc;
+    hipLaunchKernelGGL(mpc_rollout_step_kernel, dim3(grid), dim3(256), 0, s, B, ld, t == 0, o9, state, h->d_rstat, h->d_iters, status, iters);
+    MPC_HIP_CHECK(hipGetLastError());
+  }
+  h->last_status = status; h->last_iters = iters ? iters : h->d_iters;
+  return MPC_OK;
 }
 
 extern "C" int mpc_synchronize(MpcHandle *h) {

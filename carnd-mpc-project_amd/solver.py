@@ -127,6 +127,25 @@ class BatchedMPC:
             C.c_void_p(s.cuda_stream)), "mpc_telemetry_batch_device")
         return res
 
+    def rollout_torch(self, state, coeffs, yaw_lo, yaw_hi, steps, weights=None, want_hist=True, stream=None):
+        """Closed loop of src/test.cpp:79-111 for a batch: `steps` cold-started solves, each fed with the previous
+        step-1 state.  `state` [6,B] is advanced in place.  Returns hist [steps,9,B], worst status, summed iters."""
+        import torch
+        B = state.shape[1]
+        dev = state.device
+        for name, t, shape in (("state", state, (6, B)), ("coeffs", coeffs, (5, B)), ("yaw_lo", yaw_lo, (B,)), ("yaw_hi", yaw_hi, (B,))):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != shape:
+                raise ValueError("%s must be a contiguous float64 CUDA tensor of shape %s" % (name, shape))
+        res = {"hist": torch.empty((steps, _abi.NOUT, B), dtype=torch.float64, device=dev) if want_hist else None,
+               "status": torch.empty((B,), dtype=torch.int32, device=dev),
+               "iters": torch.empty((B,), dtype=torch.int32, device=dev)}
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        check(library().mpc_rollout_batch_device(
+            self._h, B, B, int(steps), state.data_ptr(), coeffs.data_ptr(), yaw_lo.data_ptr(), yaw_hi.data_ptr(),
+            weights.data_ptr() if weights is not None else None, res["hist"].data_ptr() if want_hist else None,
+            res["status"].data_ptr(), res["iters"].data_ptr(), C.c_void_p(s.cuda_stream)), "mpc_rollout_batch_device")
+        return res
+
     # -- host path (numpy arrays; copies through PCIe) ------------------------
     def solve_numpy(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False):
         f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))

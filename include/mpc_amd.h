@@ -172,6 +172,15 @@ int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const do
  *   out8 [8][ld] or NULL   run()'s own return vector */
 int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
                                double *ptsx, double *ptsy, double *cmd, double *out8, int32_t *status, void *stream);
+/* Closed-loop rollout (the pattern of src/test.cpp:79-111): `steps` times
+ * solve() and feed {x1,y1,psi1,v1,cte1,epsi1} back as the next state, cold start each time as the reference does.
+ *   state [6][ld]          in: start states; out: the state after the last step
+ *   hist  [steps][9][ld]   or NULL: solve()'s 9-vector of every step
+ *   status[ld]             worst (largest) status code over the steps;  iters[ld] or NULL: iterations summed
+ * The road polynomial and the psi-bounds stay fixed over the rollout, as in test.cpp (one fit, one run()). */
+int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int steps, double *state, const double *coeffs,
+                             const double *yaw_lo, const double *yaw_hi, const double *weights, double *hist,
+                             int32_t *status, int32_t *iters, void *stream);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
