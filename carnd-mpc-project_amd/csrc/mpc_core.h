@@ -73,13 +73,13 @@ namespace mpc {
 enum : int {
   F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
-  F_D = 2 * IT_SZ, D_N = 14,                                       /* direction */
+  F_D = 2 * IT_SZ, D_N = 8,                                        /* direction (ds, du) */
   F_GK = F_D + D_N, GK_N = 12,                                     /* gains K (HBM placement) */
   F_GF = F_GK + GK_N, GF_N = 2,                                    /* gains kff (HBM placement) */
   STAGE_SZ_LDS = F_GK,                                             /* 58 fields/stage with gains in LDS */
   STAGE_SZ_GLOBAL = F_GF + GF_N                                    /* 72 fields/stage with gains in HBM */
 };
-enum : int { D_S = 0, D_U = 6, D_LAM = 8 };                        /* direction entries */
+enum : int { D_S = 0, D_U = 6 };                                   /* direction entries */
 
 MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
   return (int64_t)(N - 1) * (gains_in_lds ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL);
@@ -93,24 +93,22 @@ MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N
  * to staged positions 22..35; sit()/sx() read them back; stage_wait<N>() waits until at most the N
  * most recent copy instructions are still in flight.  On the host build all of this degenerates to
  * direct reads. */
-enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
+enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
 /* pair stores a stage issues in each sweep (all through store2): the counted waits let exactly these
  * stay in flight besides the newest copy group */
-enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_COSTATE = 3, ST_TRIAL = IT_SZ / 2 };
+enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_TRIAL = IT_SZ / 2 };
 
 /* Plain storage for the test-only host build: one instance, fields contiguous. */
 struct HostWorkspace {
   double *base;
-  MPC_HD double &it(int k, int f) const { return base[k * STAGE_SZ_GLOBAL + f]; }
+  /* field f of iterate slot I (or I = 0 and an absolute field) of stage k */
+  MPC_HD double &it(int k, int I, int f) const { return base[k * STAGE_SZ_GLOBAL + I + f]; }
   MPC_HD double getD(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_D + j]; }
   MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_D + j] = v; }
-  MPC_HD double getK(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GK + j]; }
-  MPC_HD void setK(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GK + j] = v; }
-  MPC_HD double getF(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_GF + j]; }
-  MPC_HD void setF(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_GF + j] = v; }
-  MPC_HD void store2(int k, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + f] = a; base[k * STAGE_SZ_GLOBAL + f + 1] = b; }
+  MPC_HD void store2(int k, int I, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + I + f] = a; base[k * STAGE_SZ_GLOBAL + I + f + 1] = b; }
   MPC_HD void stage_fetch_it(int, int, int) const {}
   MPC_HD void stage_fetch_x(int, int, int) const {}
+  MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
   MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
   MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
@@ -141,6 +139,23 @@ typedef char lchar;
  * LDS: 2 buffers x 36 fields x 512 B = 36 KB per wave, 144 KB per CU at four waves.
  * All pointers are typed into their address space: accesses are global_* / ds_* instructions, never flat_*;
  * the tile base is wave-uniform and byte offsets are formed in 32 bits (saddr + voffset addressing). */
+/* Addressing: the byte offset of (stage k, field) is wave-uniform and goes through the scalar unit into the
+ * instruction's SGPR base; the only vector part is `lane16` (+ the per-lane choice of the iterate slot, whose
+ * two values differ between lanes in different solver phases).  Formed any other way the compiler keeps one
+ * pre-computed vector offset per field alive across the sweeps, spills them, and every reload sits between a
+ * prefetch and its use -- with in-order vmcnt that turns each prefetch into a synchronous load. */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* the empty asm pins the value in an SGPR at the point of use: without it the loop-invariant addresses of
+ * the sweeps' first fetches are hoisted out of the solver loop as ~20 vector pairs and spilled */
+__device__ __forceinline__ unsigned mpc_uniform(unsigned x) {
+  unsigned s = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+  asm volatile("" : "+s"(s));
+  return s;
+}
+#define MPC_UNIFORM(x) mpc_uniform((unsigned)(x))
+#else
+#define MPC_UNIFORM(x) ((unsigned)(x))
+#endif
 template <bool STAGING>
 struct TiledWorkspace {
   gdouble *tile;   /* this wave's tile */
@@ -148,40 +163,37 @@ struct TiledWorkspace {
   int lane;
   static constexpr unsigned STAGE = STAGE_SZ_GLOBAL;
   static constexpr unsigned PAIRS = STAGE_SZ_GLOBAL / 2;
-  MPC_HD gdouble &g(int k, int f) const {
-    const unsigned e = (((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 64u + (unsigned)lane) * 2u + ((unsigned)f & 1u);
-    return *(gdouble *)((gchar *)tile + e * 8u);
+  /* uniform part: row of (stage k, field f) + position inside the pair; vector part: lane and slot */
+  MPC_HD gchar *row(int k, int f) const {
+    return (gchar *)tile + MPC_UNIFORM(((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 1024u + ((unsigned)f & 1u) * 8u);
   }
-  MPC_HD gdouble &it(int k, int f) const { return g(k, f); }
+  MPC_HD unsigned voff(int I) const { return (unsigned)lane * 16u + ((unsigned)I >> 1) * 1024u; }
+  MPC_HD gdouble &it(int k, int I, int f) const { return *(gdouble *)(row(k, f) + voff(I)); }
   /* both fields of a pair (f even) with ONE 16-byte store: the number of store instructions per stage is
    * then exact, which the counted waits of the staged sweeps rely on */
-  MPC_HD void store2(int k, int f, double a, double b) const {
+  MPC_HD void store2(int k, int I, int f, double a, double b) const {
     typedef double __attribute__((ext_vector_type(2))) d2;
     typedef __attribute__((address_space(1))) d2 gd2;
-    const unsigned e = (((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 64u + (unsigned)lane) * 16u;
     d2 v; v.x = a; v.y = b;
-    *(gd2 *)((gchar *)tile + e) = v;
+    *(gd2 *)(row(k, f) + voff(I)) = v;
   }
-  MPC_HD double getD(int k, int j) const { return g(k, F_D + j); }
-  MPC_HD void setD(int k, int j, double v) const { g(k, F_D + j) = v; }
-  MPC_HD double getK(int k, int j) const { return g(k, F_GK + j); }
-  MPC_HD void setK(int k, int j, double v) const { g(k, F_GK + j) = v; }
-  MPC_HD double getF(int k, int j) const { return g(k, F_GF + j); }
-  MPC_HD void setF(int k, int j, double v) const { g(k, F_GF + j) = v; }
+  MPC_HD double getD(int k, int j) const { return it(k, 0, F_D + j); }
+  MPC_HD void setD(int k, int j, double v) const { it(k, 0, F_D + j) = v; }
   /* ---- staging ---- */
   template <int NPAIRS>
-  MPC_HD void dma(int buf, int k, int f0, int dst_pair) const {
+  MPC_HD void dma(int buf, int k, int I, int f0, int dst_pair) const {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned vo = voff(I);
     MPC_UNROLL
     for (int q = 0; q < NPAIRS; q++) {
-      const unsigned src = (((unsigned)k * PAIRS + ((unsigned)f0 >> 1) + (unsigned)q) * 64u + (unsigned)lane) * 16u;
-      const unsigned dst = (((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q) * 64u) * 16u;
-      __builtin_amdgcn_global_load_lds((gchar *)tile + src, (lchar *)lbuf + dst, 16, 0, 0);
+      const unsigned dst = MPC_UNIFORM((((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q) * 64u) * 16u);
+      __builtin_amdgcn_global_load_lds(row(k, f0 + 2 * q) + vo, (lchar *)lbuf + dst, 16, 0, 0);
     }
 #endif
   }
-  MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0); }
-  MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, F, STG_IT_OPS); }
+  MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0, 0); }
+  MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F, STG_IT_OPS); }
+  MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
   template <int N> MPC_HD void stage_wait() const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (STAGING) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -190,8 +202,8 @@ struct TiledWorkspace {
   MPC_HD double sl(int buf, int j) const {
     return lbuf[(((unsigned)buf * STG_SLOT_PAIRS + ((unsigned)j >> 1)) * 64u + (unsigned)lane) * 2u + ((unsigned)j & 1u)];
   }
-  MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)g(k, I + j); }
-  MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)g(k, F + j); }
+  MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)it(k, I, j); }
+  MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, 0, F + j); }
 };
 #endif
 
@@ -375,7 +387,7 @@ struct Solver {
       for (int i = 0; i < 6; i++) s[i] = st[i];
     } else {
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) s[i] = ws.it(k - 1, I + F_S + i);
+      for (int i = 0; i < 6; i++) s[i] = ws.it(k - 1, I, F_S + i);
     }
   }
 
@@ -495,7 +507,7 @@ struct Solver {
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
         const double idet = frcp(det);
-        ws.store2(0, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
+        ws.store2(0, 0, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -562,8 +574,8 @@ struct Solver {
       }
       const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
       MPC_UNROLL
-      for (int j = 0; j < 6; j += 2) { ws.store2(k, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
-      ws.store2(k, F_GF, kfd, kfa);
+      for (int j = 0; j < 6; j += 2) { ws.store2(k, 0, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, 0, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
+      ws.store2(k, 0, F_GF, kfd, kfa);
       /* ---- value function of stage k ---- */
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
@@ -642,8 +654,8 @@ struct Solver {
       const double n3 = d3 + dt * da - rsc * L.c[3];
       const double n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
       const double n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
-      ws.store2(k, F_D + D_S + 0, n0, n1); ws.store2(k, F_D + D_S + 2, n2, n3);
-      ws.store2(k, F_D + D_S + 4, n4, n5); ws.store2(k, F_D + D_U + 0, dd, da);
+      ws.store2(k, 0, F_D + D_S + 0, n0, n1); ws.store2(k, 0, F_D + D_S + 2, n2, n3);
+      ws.store2(k, 0, F_D + D_S + 4, n4, n5); ws.store2(k, 0, F_D + D_U + 0, dd, da);
       const double q2 = n2, q3 = n3, q4 = n4, q5 = n5, qd = dd, qa = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
       const double xs[4] = {sn[2], sn[3], delta, acc};
@@ -676,200 +688,188 @@ struct Solver {
   }
 
   /* ------------------------------------------------------------------ */
-  /* backward costate sweep: full-step multipliers lam+ -> dlam           */
-  /* (the state rows of the Newton system, solved for lam+)               */
+  /* costate + trial point in ONE descending sweep.                       */
+  /*  - costate: the state rows of the Newton system solved for the       */
+  /*    full-step multipliers lam+_k (backward recursion), dlam = lam+ - lam */
+  /*  - trial: iterate(cur) + alpha * direction -> slot 1-cur, with       */
+  /*    residuals, objective, barrier and the optimality-error pieces.    */
+  /* Every trial quantity is local to a stage (or to two neighbouring     */
+  /* ones), so the trial point can be evaluated in the costate's order;   */
+  /* dlam never goes to memory, and a backtracking trial simply repeats   */
+  /* the (cheap) costate arithmetic.  alpha scales (ds,du), alpha_l scales */
+  /* dlam, alpha_z the bound duals; with_costate = false evaluates the    */
+  /* point as it stands (start point).  lmax returns max |dlam|.          */
+  /* Step k (M..0) works on record k-1 = (s_k, u_{k-1}, lam_k, duals) and */
+  /* on transition k = (s_k, u_k) -> s_{k+1} whose other inputs are       */
+  /* carried in registers from step k+1.                                  */
   /* ------------------------------------------------------------------ */
-  MPC_HD void costate(double dw) {
-    const int I = it(cur);
-    const double hxy = (lsm ? 1.0 : 0.0) + dw;
-    double L0, L1, L2, L3, L4, L5; /* lam+_{k+1}: x,y,psi,v,c,e */
-    /* staging: record j (iterate + direction of stage j) in buffer (M-1-j)&1; stage k uses record k-1
-     * directly and (delta_k, a_k, lam_{k+1}, d delta_k) of record k from registers */
-    ws.template stage_wait<0>();
-    ws.stage_fetch_it(0, M - 1, I);
-    ws.stage_fetch_x(0, M - 1, F_D);
-    ws.template stage_wait<0>();
-    double sn[6];
-    MPC_UNROLL
-    for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
-    double delta, acc, lx, ly, lp, lc, le, ddk;
-    {
-      const int ks = M - 1;
-      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(sn[2], sn[3], sn[4], sn[5], ws.sit(0, ks, I, F_ZL + 0), ws.sit(0, ks, I, F_ZU + 0), ws.sit(0, ks, I, F_ZL + 1),
-                  ws.sit(0, ks, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      L0 = -(hxy * ws.sx(0, ks, F_D, D_S + 0));
-      L1 = -(hxy * ws.sx(0, ks, F_D, D_S + 1));
-      L2 = -(gp + (Hpp + dw) * ws.sx(0, ks, F_D, D_S + 2));
-      L3 = -(gv + (Hvv + dw) * ws.sx(0, ks, F_D, D_S + 3));
-      L4 = -(gc + (Hcc + dw) * ws.sx(0, ks, F_D, D_S + 4));
-      L5 = -(ge + (Hee + dw) * ws.sx(0, ks, F_D, D_S + 5));
-      lx = ws.sit(0, ks, I, F_LAM + 0); ly = ws.sit(0, ks, I, F_LAM + 1); lp = ws.sit(0, ks, I, F_LAM + 2);
-      const double l3 = ws.sit(0, ks, I, F_LAM + 3);
-      lc = ws.sit(0, ks, I, F_LAM + 4); le = ws.sit(0, ks, I, F_LAM + 5);
-      ws.store2(ks, F_D + D_LAM + 0, L0 - lx, L1 - ly); ws.store2(ks, F_D + D_LAM + 2, L2 - lp, L3 - l3);
-      ws.store2(ks, F_D + D_LAM + 4, L4 - lc, L5 - le);
-      delta = ws.sit(0, ks, I, F_U + 0); acc = ws.sit(0, ks, I, F_U + 1);
-      ddk = ws.sx(0, ks, F_D, D_U + 0);
-    }
-    if (M >= 2) { ws.stage_fetch_it(1, M - 2, I); ws.stage_fetch_x(1, M - 2, F_D); }
-    for (int k = M - 1; k >= 1; --k) {
-      const int bk = (M - k) & 1;                    /* buffer of record k-1 */
-      if (k >= 2) {
-        ws.stage_fetch_it(bk ^ 1, k - 2, I);
-        ws.stage_fetch_x(bk ^ 1, k - 2, F_D);
-        if (k == M - 1) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
-        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_COSTATE>();
-      } else ws.template stage_wait<0>();
-      double sk[6];
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) sk[i] = ws.sit(bk, k - 1, I, F_S + i);
-      const double v = sk[3];
-      Lin L;
-      linearise(sk, delta, acc, sn, L);   /* the residual part is unused here and is eliminated */
-      const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
-      const double dxk = ws.sx(bk, k - 1, F_D, D_S + 0), dyk = ws.sx(bk, k - 1, F_D, D_S + 1), dpk = ws.sx(bk, k - 1, F_D, D_S + 2);
-      const double dvk = ws.sx(bk, k - 1, F_D, D_S + 3), dck = ws.sx(bk, k - 1, F_D, D_S + 4), dek = ws.sx(bk, k - 1, F_D, D_S + 5);
-      const double lo0 = ws.sit(bk, k - 1, I, F_LAM + 0), lo1 = ws.sit(bk, k - 1, I, F_LAM + 1), lo2 = ws.sit(bk, k - 1, I, F_LAM + 2);
-      const double lo3 = ws.sit(bk, k - 1, I, F_LAM + 3), lo4 = ws.sit(bk, k - 1, I, F_LAM + 4), lo5 = ws.sit(bk, k - 1, I, F_LAM + 5);
-      const double n_delta = ws.sit(bk, k - 1, I, F_U + 0), n_acc = ws.sit(bk, k - 1, I, F_U + 1);
-      const double n_ddk = ws.sx(bk, k - 1, F_D, D_U + 0);
-      const double vdt = v * dt, Apv = delta * dtLf;
-      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-      state_terms(sk[2], v, sk[4], sk[5], ws.sit(bk, k - 1, I, F_ZL + 0), ws.sit(bk, k - 1, I, F_ZU + 0),
-                  ws.sit(bk, k - 1, I, F_ZL + 1), ws.sit(bk, k - 1, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-      /* curvature of stage k */
-      const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
-      const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
-      const double L25 = L2 + L5;
-      const double n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * dxk;
-      const double n1 = L1 - L4 - hxy * dyk;
-      const double n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * dpk - Hpv * dvk;
-      const double n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * dpk -
-                        (Hvv + dw) * dvk - Hev * dek - Hvd * ddk;
-      const double n4 = -gc - (Hcc + dw) * dck;
-      const double n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * dek - Hev * dvk;
-      L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
-      ws.store2(k - 1, F_D + D_LAM + 0, L0 - lo0, L1 - lo1); ws.store2(k - 1, F_D + D_LAM + 2, L2 - lo2, L3 - lo3);
-      ws.store2(k - 1, F_D + D_LAM + 4, L4 - lo4, L5 - lo5);
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) sn[i] = sk[i];
-      delta = n_delta; acc = n_acc; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5; ddk = n_ddk;
-    }
-  }
-
-  /* ------------------------------------------------------------------ */
-  /* trial point: iterate(cur) + alpha * direction -> slot 1-cur, with    */
-  /* residuals, objective, barrier, and the optimality error pieces.      */
-  /* ------------------------------------------------------------------ */
-  MPC_HD Eval trial(double alpha, double alpha_z) {
+  MPC_HD Eval costate_trial(double dw, double alpha, double alpha_l, double alpha_z, bool with_costate, double &lmax) {
     const int I = it(cur), J = it(1 - cur);
+    const double hxy = (lsm ? 1.0 : 0.0) + dw;
     Eval R;
     R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.ok = true;
-    double s[6] = {st[0], st[1], st[2], st[3], st[4], st[5]};
-    double lamk[6] = {0, 0, 0, 0, 0, 0};   /* lam_k of the trial point (k>=1) */
-    double zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0; /* zl_psi, zu_psi, zl_v, zu_v of s_k */
-    double rdel_prev = 0, delprev = 0;
+    lmax = 0.0;
     const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
-    /* staging: stage k's iterate record and direction in buffer k&1, stage k+1 requested meanwhile */
+    /* carried from step k+1 -- current iterate: s_{k+1}, u_k, lam_{k+1}, d(delta_k), lam+_{k+1} */
+    double sn_o[6] = {0, 0, 0, 0, 0, 0}, del_o = 0, acc_o = 0, lx = 0, ly = 0, lp = 0, lc = 0, le = 0, ddk = 0;
+    double L0 = 0, L1 = 0, L2 = 0, L3 = 0, L4 = 0, L5 = 0;
+    /* -- trial point: s_{k+1}, lam_{k+1}, u_k, duals of u_k, delta_{k+1} */
+    double sn_t[6] = {0, 0, 0, 0, 0, 0}, ln_t[6] = {0, 0, 0, 0, 0, 0}, del_t = 0, acc_t = 0, del_nx = 0;
+    double zdl_t = 0, zdu_t = 0, zal_t = 0, zau_t = 0;
+    /* staging: record j (iterate + direction of stage j) in buffer (M-1-j)&1 */
     ws.template stage_wait<0>();
-    ws.stage_fetch_it(0, 0, I);
-    ws.stage_fetch_x(0, 0, F_D);
-    for (int k = 0; k < M; ++k) {
-      const int bf = k & 1;
-      if (k + 1 < M) {
-        ws.stage_fetch_it(bf ^ 1, k + 1, I);
-        ws.stage_fetch_x(bf ^ 1, k + 1, F_D);
-        if (k == 0) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
-        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_TRIAL>();
-      } else ws.template stage_wait<0>();
-      const double delo = ws.sit(bf, k, I, F_U + 0), acco = ws.sit(bf, k, I, F_U + 1);
-      const double ddel = ws.sx(bf, k, F_D, D_U + 0), dacc = ws.sx(bf, k, F_D, D_U + 1);
-      const double delta = delo + alpha * ddel;
-      const double acc = acco + alpha * dacc;
-      double so[6], dso[6], sn[6], ln[6];
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) {
-        so[i] = ws.sit(bf, k, I, F_S + i); dso[i] = ws.sx(bf, k, F_D, D_S + i);
-        sn[i] = so[i] + alpha * dso[i];
-        ln[i] = ws.sit(bf, k, I, F_LAM + i) + alpha * ws.sx(bf, k, F_D, D_LAM + i);
+    ws.stage_fetch_it(0, M - 1, I);
+    ws.stage_fetch_d(0, M - 1);
+    for (int k = M; k >= 0; --k) {
+      const int bk = (M - k) & 1;                    /* buffer of record k-1 */
+      double s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
+      double zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0;     /* trial duals of psi_k, v_k: zl_psi, zu_psi, zl_v, zu_v */
+      double n_del_o = 0, n_acc_o = 0, n_ddk = 0, lo0 = 0, lo1 = 0, lo2 = 0, lo4 = 0, lo5 = 0;
+      double n_del_t = 0, n_acc_t = 0, n_zdl = 0, n_zdu = 0, n_zal = 0, n_zau = 0;
+      if (k >= 1) {
+        if (k >= 2) {
+          ws.stage_fetch_it(bk ^ 1, k - 2, I);
+          ws.stage_fetch_d(bk ^ 1, k - 2);
+          if (k == M) ws.template stage_wait<STG_IT_OPS + STG_D_OPS>();
+          else ws.template stage_wait<STG_IT_OPS + STG_D_OPS + ST_TRIAL>();
+        } else ws.template stage_wait<0>();
+        const int r = k - 1;
+        double ds[6];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) { s_o[i] = ws.sit(bk, r, I, F_S + i); ds[i] = ws.sx(bk, r, F_D, D_S + i); }
+        const double lo3 = ws.sit(bk, r, I, F_LAM + 3);
+        lo0 = ws.sit(bk, r, I, F_LAM + 0); lo1 = ws.sit(bk, r, I, F_LAM + 1); lo2 = ws.sit(bk, r, I, F_LAM + 2);
+        lo4 = ws.sit(bk, r, I, F_LAM + 4); lo5 = ws.sit(bk, r, I, F_LAM + 5);
+        n_del_o = ws.sit(bk, r, I, F_U + 0); n_acc_o = ws.sit(bk, r, I, F_U + 1);
+        const double ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
+        n_ddk = ddel;
+        /* ---- costate: lam+_k ---- */
+        double dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
+        if (with_costate) {
+          double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+          state_terms(s_o[2], s_o[3], s_o[4], s_o[5], ws.sit(bk, r, I, F_ZL + 0), ws.sit(bk, r, I, F_ZU + 0),
+                      ws.sit(bk, r, I, F_ZL + 1), ws.sit(bk, r, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+          double n0, n1, n2, n3, n4, n5;
+          if (k == M) {
+            n0 = -(hxy * ds[0]);
+            n1 = -(hxy * ds[1]);
+            n2 = -(gp + (Hpp + dw) * ds[2]);
+            n3 = -(gv + (Hvv + dw) * ds[3]);
+            n4 = -(gc + (Hcc + dw) * ds[4]);
+            n5 = -(ge + (Hee + dw) * ds[5]);
+          } else {
+            const double v = s_o[3];
+            Lin L;
+            linearise(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
+            const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+            const double vdt = v * dt, Apv = del_o * dtLf;
+            /* curvature of stage k */
+            const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
+            const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+            const double L25 = L2 + L5;
+            n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * ds[0];
+            n1 = L1 - L4 - hxy * ds[1];
+            n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds[2] - Hpv * ds[3];
+            n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * ds[2] -
+                 (Hvv + dw) * ds[3] - Hev * ds[5] - Hvd * ddk;
+            n4 = -gc - (Hcc + dw) * ds[4];
+            n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * ds[5] - Hev * ds[3];
+          }
+          L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
+          dl0 = L0 - lo0; dl1 = L1 - lo1; dl2 = L2 - lo2; dl3 = L3 - lo3; dl4 = L4 - lo4; dl5 = L5 - lo5;
+          lmax = fmax(lmax, fmax(fmax(fmax(fabs(dl0), fabs(dl1)), fmax(fabs(dl2), fabs(dl3))), fmax(fabs(dl4), fabs(dl5))));
+        }
+        /* ---- trial: record k-1 ---- */
+        lam_t[0] = lo0 + alpha_l * dl0; lam_t[1] = lo1 + alpha_l * dl1; lam_t[2] = lo2 + alpha_l * dl2;
+        lam_t[3] = lo3 + alpha_l * dl3; lam_t[4] = lo4 + alpha_l * dl4; lam_t[5] = lo5 + alpha_l * dl5;
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) s_t[i] = s_o[i] + alpha * ds[i];
+        n_del_t = n_del_o + alpha * ddel;
+        n_acc_t = n_acc_o + alpha * dacc;
+        MPC_UNROLL
+        for (int i = 0; i < 6; i += 2) {
+          ws.store2(r, J, F_S + i, s_t[i], s_t[i + 1]);
+          ws.store2(r, J, F_LAM + i, lam_t[i], lam_t[i + 1]);
+          R.lsum += fabs(lam_t[i]) + fabs(lam_t[i + 1]);
+        }
+        ws.store2(r, J, F_U, n_del_t, n_acc_t);
+        /* duals of psi_k, v_k, delta_{k-1}, a_{k-1} */
+        const double xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
+        const double xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
+        const double dxb[4] = {ds[2], ds[3], ddel, dacc};
+        const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+        double zln[4], zun[4], prod = 1.0;
+        MPC_UNROLL
+        for (int b = 0; b < 4; b++) {
+          const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
+          const double zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
+          const double dzl = mu * islo - zl - zl * islo * dxb[b];
+          const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
+          const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
+          if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
+          const double isl = frcp(sl), isu = frcp(su);
+          double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
+          /* kappa_sigma safeguard, W&B eq. (16) */
+          a = fmax(fmin(a, ksm * isl), ksi * isl);
+          c = fmax(fmin(c, ksm * isu), ksi * isu);
+          zln[b] = a; zun[b] = c;
+          R.zsum += a + c;
+          const double pl = sl * a, pu = su * c;
+          R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
+          prod *= sl * su;
+        }
+        ws.store2(r, J, F_ZL + 0, zln[0], zln[1]); ws.store2(r, J, F_ZL + 2, zln[2], zln[3]);
+        ws.store2(r, J, F_ZU + 0, zun[0], zun[1]); ws.store2(r, J, F_ZU + 2, zun[2], zun[3]);
+        R.L += log(prod);
+        zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
+        n_zdl = zln[2]; n_zdu = zun[2]; n_zal = zln[3]; n_zau = zun[3];
+        /* objective terms of (s_k, u_{k-1}) */
+        const double dv = s_t[3] - vref;
+        R.f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
+      } else {
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
       }
-      MPC_UNROLL
-      for (int i = 0; i < 6; i += 2) {
-        ws.store2(k, J + F_S + i, sn[i], sn[i + 1]);
-        ws.store2(k, J + F_LAM + i, ln[i], ln[i + 1]);
-        R.lsum += fabs(ln[i]) + fabs(ln[i + 1]);
+      if (k < M) {
+        /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
+        Lin L;
+        linearise(s_t, del_t, acc_t, sn_t, L);
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) { R.theta += fabs(L.c[i]); R.cinf = fmax(R.cinf, fabs(L.c[i])); }
+        const double ddl = (k >= 1) ? del_t - n_del_t : 0.0;          /* delta_k - delta_{k-1} */
+        const double ddn = (k + 1 < M) ? del_nx - del_t : 0.0;        /* delta_{k+1} - delta_k */
+        if (k >= 1) R.f += wdd * ddl * ddl;
+        const double v = s_t[3], vdt = v * dt, Apv = del_t * dtLf, Bp = v * dtLf;
+        const double l25 = ln_t[2] + ln_t[5];
+        /* rows of u_k */
+        const double rd = df * (2.0 * wd * del_t + 2.0 * wdd * ddl - 2.0 * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
+        const double ra = -dt * ln_t[3] - zal_t + zau_t;
+        R.dinf = fmax(R.dinf, fmax(fabs(rd), fabs(ra)));
+        /* rows of s_k (k>=1) with A_k of the trial point */
+        if (k >= 1) {
+          const double r0 = lam_t[0] - (ln_t[0] + L.fp * ln_t[4] - L.g1 * ln_t[5]);
+          const double r1 = lam_t[1] - (ln_t[1] - ln_t[4]);
+          const double r2 = lam_t[2] - (-vdt * L.sp * ln_t[0] + vdt * L.cp * ln_t[1] + l25) - zs0 + zs1;
+          const double r3 = df * 2.0 * wv * (s_t[3] - vref) + lam_t[3] -
+                            (dt * L.cp * ln_t[0] + dt * L.sp * ln_t[1] + Apv * l25 + ln_t[3] + dt * L.se * ln_t[4]) - zs2 + zs3;
+          const double r4 = df * 2.0 * wc * s_t[4] + lam_t[4];
+          const double r5 = df * 2.0 * we * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
+          R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+        }
+      } else {
+        /* terminal state rows */
+        const double r2 = lam_t[2] - zs0 + zs1;
+        const double r3 = df * 2.0 * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
+        const double r4 = df * 2.0 * wc * s_t[4] + lam_t[4];
+        const double r5 = df * 2.0 * we * s_t[5] + lam_t[5];
+        R.dinf = fmax(R.dinf, fmax(fmax(fabs(lam_t[0]), fabs(lam_t[1])), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
       }
-      ws.store2(k, J + F_U, delta, acc);
-      Lin L;
-      linearise(s, delta, acc, sn, L);
+      /* carry to step k-1 */
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) { R.theta += fabs(L.c[i]); R.cinf = fmax(R.cinf, fabs(L.c[i])); }
-      /* duals of psi_{k+1}, v_{k+1}, delta_k, a_k */
-      const double xo[4] = {so[2], so[3], delo, acco};
-      const double xn[4] = {sn[2], sn[3], delta, acc};
-      const double dxb[4] = {dso[2], dso[3], ddel, dacc};
-      const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
-      double zln[4], zun[4], prod = 1.0;
-      MPC_UNROLL
-      for (int b = 0; b < 4; b++) {
-        const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
-        const double zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
-        const double dzl = mu * islo - zl - zl * islo * dxb[b];
-        const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
-        const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
-        if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
-        const double isl = frcp(sl), isu = frcp(su);
-        double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
-        /* kappa_sigma safeguard, W&B eq. (16) */
-        a = fmax(fmin(a, ksm * isl), ksi * isl);
-        c = fmax(fmin(c, ksm * isu), ksi * isu);
-        zln[b] = a; zun[b] = c;
-        R.zsum += a + c;
-        const double pl = sl * a, pu = su * c;
-        R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
-        prod *= sl * su;
-      }
-      ws.store2(k, J + F_ZL + 0, zln[0], zln[1]); ws.store2(k, J + F_ZL + 2, zln[2], zln[3]);
-      ws.store2(k, J + F_ZU + 0, zun[0], zun[1]); ws.store2(k, J + F_ZU + 2, zun[2], zun[3]);
-      R.L += log(prod);
-      /* objective */
-      const double dv = sn[3] - vref;
-      R.f += wc * sn[4] * sn[4] + we * sn[5] * sn[5] + wv * dv * dv + wd * delta * delta;
-      const double ddl = (k > 0) ? delta - delprev : 0.0;
-      if (k > 0) R.f += wdd * ddl * ddl;
-      /* dual infeasibility: rows of s_k (k>=1) and u_k; A_k, B_k of the trial point */
-      const double v = s[3], vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
-      const double l25 = ln[2] + ln[5];
-      if (k > 0) {
-        const double r0 = lamk[0] - (ln[0] + L.fp * ln[4] - L.g1 * ln[5]);
-        const double r1 = lamk[1] - (ln[1] - ln[4]);
-        const double r2 = lamk[2] - (-vdt * L.sp * ln[0] + vdt * L.cp * ln[1] + l25) - zs0 + zs1;
-        const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] -
-                          (dt * L.cp * ln[0] + dt * L.sp * ln[1] + Apv * l25 + ln[3] + dt * L.se * ln[4]) - zs2 + zs3;
-        const double r4 = df * 2.0 * wc * s[4] + lamk[4];
-        const double r5 = df * 2.0 * we * s[5] + lamk[5] - vdt * L.ce * ln[4];
-        R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
-        /* finish the delta_{k-1} row now that delta_k is known */
-        R.dinf = fmax(R.dinf, fabs(rdel_prev - df * 2.0 * wdd * ddl));
-      }
-      rdel_prev = df * (2.0 * wd * delta + 2.0 * wdd * ddl) - Bp * l25 - zln[2] + zun[2];
-      const double ra = -dt * ln[3] - zln[3] + zun[3];
-      R.dinf = fmax(R.dinf, fabs(ra));
-      /* carry to the next stage */
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) { s[i] = sn[i]; lamk[i] = ln[i]; }
-      zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
-      delprev = delta;
-    }
-    /* last delta row has no successor; terminal state rows */
-    R.dinf = fmax(R.dinf, fabs(rdel_prev));
-    {
-      const double r2 = lamk[2] - zs0 + zs1;
-      const double r3 = df * 2.0 * wv * (s[3] - vref) + lamk[3] - zs2 + zs3;
-      const double r4 = df * 2.0 * wc * s[4] + lamk[4];
-      const double r5 = df * 2.0 * we * s[5] + lamk[5];
-      R.dinf = fmax(R.dinf, fmax(fmax(fabs(lamk[0]), fabs(lamk[1])), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+      for (int i = 0; i < 6; i++) { sn_o[i] = s_o[i]; sn_t[i] = s_t[i]; ln_t[i] = lam_t[i]; }
+      del_nx = del_t;
+      del_t = n_del_t; acc_t = n_acc_t; zdl_t = n_zdl; zdu_t = n_zdu; zal_t = n_zal; zau_t = n_zau;
+      del_o = n_del_o; acc_o = n_acc_o; ddk = n_ddk; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5;
     }
     if (!(R.theta == R.theta) || !(R.f == R.f) || !(R.L == R.L) || !(R.dinf == R.dinf)) R.ok = false;
     return R;
@@ -911,11 +911,11 @@ struct Solver {
   MPC_HD void start_point() {
     for (int k = 0; k < M; ++k) {
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) { ws.it(k, IT0 + F_S + i) = 0.0; ws.it(k, IT0 + F_LAM + i) = 0.0; }
-      ws.it(k, IT0 + F_S + 2) = psi_start;
-      ws.it(k, IT0 + F_U + 0) = 0.0; ws.it(k, IT0 + F_U + 1) = 0.0;
+      for (int i = 0; i < 6; i++) { ws.it(k, IT0, F_S + i) = 0.0; ws.it(k, IT0, F_LAM + i) = 0.0; }
+      ws.it(k, IT0, F_S + 2) = psi_start;
+      ws.it(k, IT0, F_U + 0) = 0.0; ws.it(k, IT0, F_U + 1) = 0.0;
       MPC_UNROLL
-      for (int b = 0; b < 4; b++) { ws.it(k, IT0 + F_ZL + b) = 1.0; ws.it(k, IT0 + F_ZU + b) = 1.0; }
+      for (int b = 0; b < 4; b++) { ws.it(k, IT0, F_ZL + b) = 1.0; ws.it(k, IT0, F_ZU + b) = 1.0; }
       MPC_UNROLL
       for (int i = 0; i < D_N; i++) ws.setD(k, i, 0.0);
     }
@@ -1000,7 +1000,7 @@ struct Solver {
     enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
     cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
     int phase = PH_EVAL0, iter = 0;
-    double alpha = 0.0, alpha_z = 0.0;
+    double alpha = 0.0, alpha_l = 0.0, alpha_z = 0.0, dw_cur = 0.0;
     double theta_max = 0.0, theta_min = 0.0, dw_last = 0.0;
     double theta_k = 0.0, phi_k = 0.0, pth = 0.0, pdp = 0.0, amin = 0.0;   /* line-search state */
     bool tiny = false;
@@ -1035,30 +1035,11 @@ struct Solver {
           else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
           if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
         }
-        if (okb) {
-          forward();
-          costate(dw);
-        }
+        if (okb) forward();
+        dw_cur = dw;
         if (phase == PH_LS) {
-          double lmax = 0.0;
-          if (okb) {
-            for (int k = 0; k < M; ++k) {
-              MPC_UNROLL
-              for (int i = 0; i < 6; i++) lmax = fmax(lmax, fabs(ws.getD(k, D_LAM + i)));
-            }
-          }
-          lsm = false;
-          const bool use = okb && (lmax <= 1000.0);
-          for (int k = 0; k < M; ++k) {
-            MPC_UNROLL
-            for (int i = 0; i < 8; i++) ws.setD(k, i, 0.0);
-            if (!use) {
-              MPC_UNROLL
-              for (int i = 0; i < 6; i++) ws.setD(k, D_LAM + i, 0.0);
-            }
-          }
-          if (!use) { phase = PH_DIR; continue; }
-          alpha = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
+          if (!okb) { lsm = false; phase = PH_DIR; continue; }
+          alpha = 0.0; alpha_l = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
         } else {
           if (dw > 0.0) { dw_last = dw; n_reg++; }
           /* filter line search, W&B algorithm A */
@@ -1070,10 +1051,11 @@ struct Solver {
             amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
           } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
           tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
-          alpha = amax; alpha_z = az;
+          alpha = amax; alpha_l = amax; alpha_z = az;
         }
       }
-      const Eval T = trial(alpha, alpha_z);
+      double lmax;
+      const Eval T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
       if (phase == PH_EVAL0) {
         E = T; cur = 1;
         if (!E.ok) return MPC_STATUS_NUMERIC;
@@ -1082,9 +1064,13 @@ struct Solver {
         continue;
       }
       if (phase == PH_LS) {
-        E = T; cur = 1 - cur;
-        if (!E.ok) return MPC_STATUS_NUMERIC;
+        lsm = false;
         phase = PH_DIR;
+        /* estimates above constr_mult_init_max = 1000 are discarded (the iterate stays as it is) */
+        if (lmax <= 1000.0) {
+          E = T; cur = 1 - cur;
+          if (!E.ok) return MPC_STATUS_NUMERIC;
+        }
         continue;
       }
       /* acceptance test of the line search */
@@ -1114,7 +1100,7 @@ struct Solver {
         continue;
       }
       if (tiny) return MPC_STATUS_LINESEARCH;
-      alpha *= 0.5;
+      alpha *= 0.5; alpha_l = alpha;
       if (alpha < amin) return MPC_STATUS_LINESEARCH;
       phase = PH_BACKTRACK;
     }
@@ -1125,14 +1111,14 @@ struct Solver {
   MPC_HD void unpack(OutF out, TrajF traj, bool want_traj) const {
     const int I = it(cur);
     MPC_UNROLL
-    for (int i = 0; i < 6; i++) out(i) = ws.it(0, I + F_S + i);
-    out(6) = ws.it(0, I + F_U + 0);
-    out(7) = ws.it(0, I + F_U + 1);
+    for (int i = 0; i < 6; i++) out(i) = ws.it(0, I, F_S + i);
+    out(6) = ws.it(0, I, F_U + 0);
+    out(7) = ws.it(0, I, F_U + 1);
     out(8) = E.f + cost0;
     if (want_traj) {
       const int N = P.N;
       traj(0) = st[0]; traj(N) = st[1];
-      for (int k = 0; k < M; ++k) { traj(k + 1) = ws.it(k, I + F_S + 0); traj(N + k + 1) = ws.it(k, I + F_S + 1); }
+      for (int k = 0; k < M; ++k) { traj(k + 1) = ws.it(k, I, F_S + 0); traj(N + k + 1) = ws.it(k, I, F_S + 1); }
     }
   }
 };
