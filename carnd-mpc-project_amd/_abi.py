@@ -56,7 +56,7 @@ class MpcBatchStats(C.Structure):
 EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_params", "mpc_destroy",
            "mpc_last_error", "mpc_abi_version", "mpc_solve_batch_device", "mpc_solve_batch_host",
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
-           "mpc_telemetry_batch_device", "mpc_rollout_batch_device"]
+           "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext"]
 
 _lib = None
 
@@ -97,6 +97,7 @@ def library():
     L.mpc_synchronize.argtypes = [C.c_void_p]
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]
     L.mpc_debug_math.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 4
+    L.mpc_debug_math_ext.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 6
     L.mpc_run_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
     L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
                                              [C.c_void_p])

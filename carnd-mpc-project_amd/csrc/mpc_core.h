@@ -231,25 +231,92 @@ MPC_HD double hpow(double x, double p) {
   return pow(x, p);
 #endif
 }
+/* An fp64 constant for a polynomial kernel, materialised in a scalar register pair AT THE POINT OF USE
+ * (two s_mov_b32, which issue beside the vector work).  gfx9 encodings have no 64-bit literals, so the
+ * compiler otherwise parks every coefficient in an accumulation register and pays two v_accvgpr_read plus
+ * two v_mov per Horner step -- four overhead instructions per FMA in the hottest loops. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double mpc_kc(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+#define MPC_K(c) mpc_kc(c)
+#else
+#define MPC_K(c) (c)
+#endif
+
 /* sin and cos together for the moderate angles of this model (psi, epsi): Cody-Waite reduction by
- * pi/2 (two FMAs, exact enough for |x| < 1e5) and the classic minimax kernels on [-pi/4, pi/4]
- * (coefficients as published in fdlibm's k_sin.c / k_cos.c); larger arguments take libm's path. */
+ * pi/2 (two FMAs: the products are exact inside the FMA, so the reduction holds while the quadrant fits an
+ * int, |x| < 1e9) and the classic minimax kernels on [-pi/4, pi/4]
+ * (coefficients as published in fdlibm's k_sin.c / k_cos.c).  libm's general path (Payne-Hanek reduction) is
+ * deliberately not linked in: it costs ~60 permanently occupied registers for its constants. */
 MPC_HD void fsincos(double x, double *sn, double *cs) {
-  if (!(fabs(x) < 1.0e5)) { ::sincos(x, sn, cs); return; }
-  const double kf = rint(x * 6.36619772367581382433e-01);
-  double r = fma(-kf, 1.57079632679489655800e+00, x);
-  r = fma(-kf, 6.12323399573676603587e-17, r);
+  if (!(fabs(x) < 1.0e9)) x = NAN;   /* no such angle in this model: the evaluation is flagged, the trial step rejected */
+  const double kf = rint(x * MPC_K(6.36619772367581382433e-01));
+  double r = fma(-kf, MPC_K(1.57079632679489655800e+00), x);
+  r = fma(-kf, MPC_K(6.12323399573676603587e-17), r);
   const double z = r * r;
-  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  double ps = MPC_K(1.58969099521155010221e-10);
+  ps = fma(z, ps, MPC_K(-2.50507602534068634195e-08));
+  ps = fma(z, ps, MPC_K(2.75573137070700676789e-06));
+  ps = fma(z, ps, MPC_K(-1.98412698298579493134e-04));
+  ps = fma(z, ps, MPC_K(8.33333333332248946124e-03));
+  ps = fma(z, ps, MPC_K(-1.66666666666666324348e-01));
+  double pc = MPC_K(-1.13596475577881948265e-11);
+  pc = fma(z, pc, MPC_K(2.08757232129817482790e-09));
+  pc = fma(z, pc, MPC_K(-2.75573143513906633035e-07));
+  pc = fma(z, pc, MPC_K(2.48015872894767294178e-05));
+  pc = fma(z, pc, MPC_K(-1.38888888888741095749e-03));
+  pc = fma(z, pc, MPC_K(4.16666666666666019037e-02));
   const double s0 = fma(r * z, ps, r);
   const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
   const int q = (int)kf & 3;
   const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
   *sn = (q & 2) ? -s1 : s1;
   *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+/* atan for the road slope f'(x):  |x| > 1 -> pi/2 - atan(1/|x|);  on [0,1]  atan(t) = t + t z q(z), z = t^2,
+ * q of degree 19 (interpolant at the Chebyshev nodes of [0,1], computed with 60 digits; approximation error
+ * 8e-17, measured total error < 4.1e-16 relative), evaluated as two interleaved chains in z^2. */
+MPC_HD double fatan(double x) {
+  const double ax = fabs(x);
+  const bool inv = ax > 1.0;
+  const double t = inv ? frcp(ax) : ax;
+  const double z = t * t, w = z * z;
+  double e = MPC_K(-1.99961893779013817792e-04), o = MPC_K(1.80619546186121510795e-05);
+  e = fma(e, w, MPC_K(-3.49588597391630936939e-03)); o = fma(o, w, MPC_K(1.04960350849685147764e-03));
+  e = fma(e, w, MPC_K(-1.55351524754141767648e-02)); o = fma(o, w, MPC_K(8.36893117845016222545e-03));
+  e = fma(e, w, MPC_K(-3.12771890669963845144e-02)); o = fma(o, w, MPC_K(2.36967315800486223731e-02));
+  e = fma(e, w, MPC_K(-4.26035663260165217703e-02)); o = fma(o, w, MPC_K(3.74948681253524720991e-02));
+  e = fma(e, w, MPC_K(-5.25797333428411062251e-02)); o = fma(o, w, MPC_K(4.73774957952777867054e-02));
+  e = fma(e, w, MPC_K(-6.66656469928910422329e-02)); o = fma(o, w, MPC_K(5.88150687779365605179e-02));
+  e = fma(e, w, MPC_K(-9.09090859089193431553e-02)); o = fma(o, w, MPC_K(7.69229897103321652585e-02));
+  e = fma(e, w, MPC_K(-1.42857142853841323493e-01)); o = fma(o, w, MPC_K(1.11111110934908274839e-01));
+  e = fma(e, w, MPC_K(-3.33333333333333314830e-01)); o = fma(o, w, MPC_K(1.99999999999975308640e-01));
+  const double q = fma(o, z, e);
+  double r = fma(t * z, q, t);
+  if (inv) r = MPC_K(1.57079632679489655800e+00) - (r - MPC_K(6.12323399573676603587e-17));
+  return copysign(r, x);
+}
+
+/* natural logarithm for the barrier term: x = m 2^k with m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
+ * log m = 2s + s R(s^2) in the compensated form of fdlibm's e_log.c (coefficients Lg1..Lg7 as published
+ * there; < 1 ulp).  x > 0 and finite is the caller's business (slack products are checked before). */
+MPC_HD double flog(double x) {
+  int k;
+  double m = frexp(x, &k);                        /* m in [0.5, 1) */
+  if (m < 7.07106781186547524401e-01) { m *= 2.0; k -= 1; }
+  const double f = m - 1.0;
+  const double s = f * frcp(2.0 + f);
+  const double z = s * s, w = z * z;
+  double t1 = MPC_K(1.531383769920937332e-01), t2 = MPC_K(1.479819860511658591e-01);
+  t1 = fma(t1, w, MPC_K(2.222219843214978396e-01)); t2 = fma(t2, w, MPC_K(1.818357216161805012e-01));
+  t1 = fma(t1, w, MPC_K(3.999999999940941908e-01)); t2 = fma(t2, w, MPC_K(2.857142874366239149e-01));
+  t2 = fma(t2, w, MPC_K(6.666666666666735130e-01));
+  const double R = w * t1 + z * t2;
+  const double hfsq = 0.5 * f * f, dk = (double)k;
+  return dk * MPC_K(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * MPC_K(1.90821492927058770002e-10))) - f);
 }
 
 /* IPOPT default constants (Waechter & Biegler 2006; IPOPT 3.12 option defaults) */
@@ -362,7 +429,7 @@ struct Solver {
     L.c[2] = sn[2] - psin;
     L.c[3] = sn[3] - (s[3] + a * dt);
     L.c[4] = sn[4] - ((f - s[1]) + L.se * vdt);
-    L.c[5] = sn[5] - (psin - atan(fp));
+    L.c[5] = sn[5] - (psin - fatan(fp));
   }
 
   /* cost + barrier terms of one state s_k (k>=1): Hessian diagonal and gradient */
@@ -820,7 +887,7 @@ struct Solver {
         }
         ws.store2(r, J, F_ZL + 0, zln[0], zln[1]); ws.store2(r, J, F_ZL + 2, zln[2], zln[3]);
         ws.store2(r, J, F_ZU + 0, zun[0], zun[1]); ws.store2(r, J, F_ZU + 2, zun[2], zun[3]);
-        R.L += log(prod);
+        R.L += flog(prod);
         zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
         n_zdl = zln[2]; n_zdu = zun[2]; n_zal = zln[3]; n_zau = zun[3];
         /* objective terms of (s_k, u_{k-1}) */

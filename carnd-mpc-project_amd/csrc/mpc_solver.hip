@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256) void mpc_rollout_step_kernel(int64_t B, int64_
   if (iters) iters[i] = (first ? 0 : iters[i]) + it_step[i];
 }
 
-__global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc) {
+__global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s, c;
   mpc::fsincos(x[i], &s, &c);
   sn[i] = s; cs[i] = c; rc[i] = mpc::frcp(x[i]);
+  at[i] = mpc::fatan(x[i]); lg[i] = mpc::flog(fabs(x[i]));
 }
 
 }  // namespace
@@ -431,23 +432,28 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
   return MPC_OK;
 }
 
-extern "C" int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc) {
-  if (n < 0 || (n > 0 && (!x || !sn || !cs || !rc))) return MPC_ERR_INVALID;
+extern "C" int mpc_debug_math_ext(int device, int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg) {
+  if (n < 0 || (n > 0 && (!x || !sn || !cs || !rc || !at || !lg))) return MPC_ERR_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_last_error = "no HIP device"; return MPC_ERR_NO_DEVICE; }
   if (device >= 0) MPC_HIP_CHECK(hipSetDevice(device));
   if (n == 0) return MPC_OK;
   double *d = nullptr;
-  MPC_HIP_CHECK(hipMalloc((void **)&d, sizeof(double) * 4 * n));
+  MPC_HIP_CHECK(hipMalloc((void **)&d, sizeof(double) * 6 * n));
   hipError_t e = hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(mpc_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d, d + n, d + 2 * n, d + 3 * n);
+    hipLaunchKernelGGL(mpc_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(sn, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(cs, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(rc, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  double *outs[5] = {sn, cs, rc, at, lg};
+  for (int q = 0; q < 5 && e == hipSuccess; q++) e = hipMemcpy(outs[q], d + (q + 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) { g_last_error = std::string("mpc_debug_math: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
   return MPC_OK;
+}
+
+extern "C" int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc) {
+  if (n < 0) return MPC_ERR_INVALID;
+  std::vector<double> at((size_t)n), lg((size_t)n);
+  return mpc_debug_math_ext(device, n, x, sn, cs, rc, at.data(), lg.data());
 }

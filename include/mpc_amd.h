@@ -190,6 +190,8 @@ int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
  * sincos and IEEE division by shorter sequences, see csrc/mpc_core.h): sn[i], cs[i] = sin/cos(x[i]),
  * rc[i] = 1/x[i].  Used by the tests to bound their error on the real hardware. */
 int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc);
+/* the same plus at[i] = atan(x[i]) and lg[i] = log|x[i]| (the solver's own atan and log kernels) */
+int mpc_debug_math_ext(int device, int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg);
 
 #ifdef __cplusplus
 }

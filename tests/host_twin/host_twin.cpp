@@ -41,6 +41,9 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
 extern "C" void mpc_host_twin_math(int64_t n, const double *x, double *sn, double *cs, double *rc) {
   for (int64_t i = 0; i < n; i++) { mpc::fsincos(x[i], &sn[i], &cs[i]); rc[i] = mpc::frcp(x[i]); }
 }
+extern "C" void mpc_host_twin_math2(int64_t n, const double *x, double *at, double *lg) {
+  for (int64_t i = 0; i < n; i++) { at[i] = mpc::fatan(x[i]); lg[i] = mpc::flog(fabs(x[i])); }
+}
 
 /* MPC::run pre/post-processing of the device header, one instance at a time (struct-of-arrays I/O like the ABI):
  * pose[6][ld], pts[npts][ld] in/out, pre[15][ld] = state6 coeffs5 yaw_lo yaw_hi max_yaw_change target_speed */

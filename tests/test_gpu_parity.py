@@ -231,9 +231,18 @@ def test_device_light_math(pkg):
     rng = np.random.default_rng(3)
     x = np.concatenate([rng.uniform(-4, 4, 50000), rng.uniform(-300, 300, 50000), rng.normal(0, 1e-3, 5000),
                         10.0 ** rng.uniform(-12, 12, 20000) * rng.choice([-1.0, 1.0], 20000),
-                        np.array([np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7])])
-    sn = np.zeros_like(x); cs = np.zeros_like(x); rc = np.zeros_like(x)
+                        np.array([np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7, 9.9e8])])
+    sn = np.zeros_like(x); cs = np.zeros_like(x); rc = np.zeros_like(x); at = np.zeros_like(x); lg = np.zeros_like(x)
     from carnd_mpc_project_amd._abi import check
-    check(pkg.library().mpc_debug_math(0, len(x), x.ctypes.data, sn.ctypes.data, cs.ctypes.data, rc.ctypes.data), "mpc_debug_math")
-    assert np.max(np.abs(sn - np.sin(x))) < 4e-16 and np.max(np.abs(cs - np.cos(x))) < 4e-16
+    check(pkg.library().mpc_debug_math_ext(0, len(x), x.ctypes.data, sn.ctypes.data, cs.ctypes.data, rc.ctypes.data,
+                                        at.ctypes.data, lg.ctypes.data), "mpc_debug_math_ext")
+    m = np.abs(x) < 1e9                                                                 # the reduction's range
+    assert np.max(np.abs(sn[m] - np.sin(x[m]))) < 4e-16 and np.max(np.abs(cs[m] - np.cos(x[m]))) < 4e-16
+    assert np.isnan(sn[~m]).all() and (~m).sum() > 100
     assert np.max(np.abs(rc * x - 1.0)) < 5e-16
+    assert np.max(np.abs(at - np.arctan(x)) / np.abs(np.arctan(x))) < 6e-16          # the solver's own atan ...
+    ref = np.log(np.abs(x))
+    assert np.max(np.abs(lg - ref) / np.maximum(np.abs(ref), 1e-3)) < 5e-16             # ... and log
+    big = np.array([1e9, -4e12]); o = [np.zeros(2) for _ in range(5)]
+    check(pkg.library().mpc_debug_math_ext(0, 2, big.ctypes.data, *[a.ctypes.data for a in o]), "mpc_debug_math_ext")
+    assert np.isnan(o[0]).all() and np.isnan(o[1]).all()                                # flagged beyond |x| = 1e9

@@ -107,8 +107,20 @@ def test_twin_light_math(host_twin):
     import ctypes as C
     rng = np.random.default_rng(3)
     x = np.concatenate([rng.uniform(-4, 4, 20000), rng.uniform(-300, 300, 20000), rng.normal(0, 1e-3, 2000),
-                        np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7])])
+                        np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e5 - 1, 2e5, -3e7, 9.9e8])])
     sn = np.zeros_like(x); cs = np.zeros_like(x); rc = np.zeros_like(x)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     host_twin.mpc_host_twin_math(C.c_int64(len(x)), p(x), p(sn), p(cs), p(rc))
     assert np.max(np.abs(sn - np.sin(x))) < 4e-16 and np.max(np.abs(cs - np.cos(x))) < 4e-16
+    # beyond the reduction's range the evaluation is flagged, not wrong
+    big = np.array([1e9, -4e12, np.inf, np.nan]); o1 = np.zeros(4); o2 = np.zeros(4); o3 = np.zeros(4)
+    host_twin.mpc_host_twin_math(C.c_int64(4), p(big), p(o1), p(o2), p(o3))
+    assert np.isnan(o1).all() and np.isnan(o2).all()
+    # atan (road slope) and log (barrier): the solver's own kernels
+    xa = np.concatenate([rng.uniform(-1, 1, 20000), rng.uniform(-60, 60, 20000), 10.0 ** rng.uniform(-12, 12, 5000),
+                         np.array([0.0, 1.0, -1.0, 1.0 + 1e-16, 1e300])])
+    at = np.zeros_like(xa); lg = np.zeros_like(xa)
+    host_twin.mpc_host_twin_math2(C.c_int64(len(xa)), p(xa), p(at), p(lg))
+    assert np.max(np.abs(at - np.arctan(xa)) / np.maximum(np.abs(np.arctan(xa)), 1e-300)) < 6e-16
+    nz = xa != 0
+    assert np.max(np.abs(lg[nz] - np.log(np.abs(xa[nz]))) / np.maximum(np.abs(np.log(np.abs(xa[nz]))), 1e-3)) < 5e-16
