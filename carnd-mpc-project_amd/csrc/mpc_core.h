@@ -180,14 +180,34 @@ struct TiledWorkspace {
   MPC_HD double getD(int k, int j) const { return it(k, 0, F_D + j); }
   MPC_HD void setD(int k, int j, double v) const { it(k, 0, F_D + j) = v; }
   /* ---- staging ---- */
+  /* Copies NPAIRS consecutive pairs.  Rows are 1 KB apart in the tile AND in the LDS slot, and the
+   * instruction's immediate offset applies to both addresses, so four copies share one scalar row base and
+   * one M0 value (immediates 0, 1024, 2048, 3072).  Written as assembly because the compiler expands the
+   * builtin's offset argument back into per-copy address arithmetic (5 issue slots per copy instead of <2).
+   * The compiler does not see these as memory instructions; that only makes its own vmcnt waits more
+   * conservative (vmcnt completes in order), and the sweeps order everything staged with explicit waits. */
   template <int NPAIRS>
   MPC_HD void dma(int buf, int k, int I, int f0, int dst_pair) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned vo = voff(I);
     MPC_UNROLL
-    for (int q = 0; q < NPAIRS; q++) {
-      const unsigned dst = MPC_UNIFORM((((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q) * 64u) * 16u);
-      __builtin_amdgcn_global_load_lds(row(k, f0 + 2 * q) + vo, (lchar *)lbuf + dst, 16, 0, 0);
+    for (int q0 = 0; q0 < NPAIRS; q0 += 4) {
+      const unsigned m0v = MPC_UNIFORM((unsigned)(unsigned long)lbuf + (((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q0) * 64u) * 16u);
+      const gchar *src = row(k, f0 + 2 * q0);
+      constexpr int n = (NPAIRS - 0);
+      if (q0 + 4 <= n)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+      else if (q0 + 3 == n)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048"
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+      else if (q0 + 2 == n)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+      else
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(src), "s"(m0v) : "memory");
     }
 #endif
   }
@@ -250,30 +270,46 @@ __device__ __forceinline__ double mpc_kc(double c) {
  * int, |x| < 1e9) and the classic minimax kernels on [-pi/4, pi/4]
  * (coefficients as published in fdlibm's k_sin.c / k_cos.c).  libm's general path (Payne-Hanek reduction) is
  * deliberately not linked in: it costs ~60 permanently occupied registers for its constants. */
-MPC_HD void fsincos(double x, double *sn, double *cs) {
-  if (!(fabs(x) < 1.0e9)) x = NAN;   /* no such angle in this model: the evaluation is flagged, the trial step rejected */
-  const double kf = rint(x * MPC_K(6.36619772367581382433e-01));
-  double r = fma(-kf, MPC_K(1.57079632679489655800e+00), x);
-  r = fma(-kf, MPC_K(6.12323399573676603587e-17), r);
-  const double z = r * r;
-  double ps = MPC_K(1.58969099521155010221e-10);
-  ps = fma(z, ps, MPC_K(-2.50507602534068634195e-08));
-  ps = fma(z, ps, MPC_K(2.75573137070700676789e-06));
-  ps = fma(z, ps, MPC_K(-1.98412698298579493134e-04));
-  ps = fma(z, ps, MPC_K(8.33333333332248946124e-03));
-  ps = fma(z, ps, MPC_K(-1.66666666666666324348e-01));
-  double pc = MPC_K(-1.13596475577881948265e-11);
-  pc = fma(z, pc, MPC_K(2.08757232129817482790e-09));
-  pc = fma(z, pc, MPC_K(-2.75573143513906633035e-07));
-  pc = fma(z, pc, MPC_K(2.48015872894767294178e-05));
-  pc = fma(z, pc, MPC_K(-1.38888888888741095749e-03));
-  pc = fma(z, pc, MPC_K(4.16666666666666019037e-02));
+/* one reduced argument: r in [-pi/4, pi/4] and the quadrant */
+MPC_HD void fsincos_finish(double r, double z, double ps, double pc, int q, double *sn, double *cs) {
   const double s0 = fma(r * z, ps, r);
   const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const int q = (int)kf & 3;
   const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
   *sn = (q & 2) ? -s1 : s1;
   *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+/* two angles at once (psi and epsi of a stage): every constant is materialised once for both, and the two
+ * Horner chains interleave */
+MPC_HD void fsincos2(double xa, double xb, double *sna, double *csa, double *snb, double *csb) {
+  if (!(fabs(xa) < 1.0e9)) xa = NAN;   /* no such angle in this model: the evaluation is flagged, the trial step rejected */
+  if (!(fabs(xb) < 1.0e9)) xb = NAN;
+  double c = MPC_K(6.36619772367581382433e-01);
+  const double ka = rint(xa * c), kb = rint(xb * c);
+  c = MPC_K(1.57079632679489655800e+00);
+  double ra = fma(-ka, c, xa), rb = fma(-kb, c, xb);
+  c = MPC_K(6.12323399573676603587e-17);
+  ra = fma(-ka, c, ra); rb = fma(-kb, c, rb);
+  const double za = ra * ra, zb = rb * rb;
+  double psa = MPC_K(1.58969099521155010221e-10), psb = psa;
+#define MPC_H2(pa, pb, k) do { const double c_ = MPC_K(k); pa = fma(za, pa, c_); pb = fma(zb, pb, c_); } while (0)
+  MPC_H2(psa, psb, -2.50507602534068634195e-08);
+  MPC_H2(psa, psb, 2.75573137070700676789e-06);
+  MPC_H2(psa, psb, -1.98412698298579493134e-04);
+  MPC_H2(psa, psb, 8.33333333332248946124e-03);
+  MPC_H2(psa, psb, -1.66666666666666324348e-01);
+  double pca = MPC_K(-1.13596475577881948265e-11), pcb = pca;
+  MPC_H2(pca, pcb, 2.08757232129817482790e-09);
+  MPC_H2(pca, pcb, -2.75573143513906633035e-07);
+  MPC_H2(pca, pcb, 2.48015872894767294178e-05);
+  MPC_H2(pca, pcb, -1.38888888888741095749e-03);
+  MPC_H2(pca, pcb, 4.16666666666666019037e-02);
+#undef MPC_H2
+  fsincos_finish(ra, za, psa, pca, (int)ka & 3, sna, csa);
+  fsincos_finish(rb, zb, psb, pcb, (int)kb & 3, snb, csb);
+}
+MPC_HD void fsincos(double x, double *sn, double *cs) {
+  double s2, c2;
+  fsincos2(x, x, sn, cs, &s2, &c2);
 }
 
 /* atan for the road slope f'(x):  |x| > 1 -> pi/2 - atan(1/|x|);  on [0,1]  atan(t) = t + t z q(z), z = t^2,
@@ -413,8 +449,7 @@ struct Solver {
   /* Stage model at (s,u), MPC.cpp:142-152, and the residual against the successor state sn.
    * Recomputed wherever it is needed (see the layout comment). */
   MPC_HD void linearise(const double *s, double delta, double a, const double *sn, Lin &L) const {
-    fsincos(s[2], &L.sp, &L.cp);
-    fsincos(s[5], &L.se, &L.ce);
+    fsincos2(s[2], s[5], &L.sp, &L.cp, &L.se, &L.ce);
     double f, fp, fpp, fppp;
     poly(s[0], f, fp, fpp, fppp);
     const double q1 = 1.0 + fp * fp, iq1 = frcp(q1);
