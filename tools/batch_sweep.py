@@ -9,15 +9,16 @@ pkg = G.load_package()
 params = pkg.params_from_json(ROOT + '/tests/golden/config-fast.json')
 wp = pkg.scenarios.load_waypoints(ROOT + '/tests/golden/lake_track_waypoints.csv')
 BMAX = int(os.environ.get("BMAX", 131072))
-b = pkg.scenarios.lake_track_batch(BMAX, params, wp)
+b = pkg.scenarios.lake_track_batch(BMAX, params, wp, seed=int(os.environ.get('SEED', pkg.scenarios.DEFAULT_SEED)))
 dev = torch.device('cuda:0'); t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 for B in [int(x) for x in os.environ.get("BS", "1024,4096,8192,16384,32768,49152,65536,98304,131072").split(",")]:
     st, cf, yl, yh = t(b['state'][:, :B]), t(b['coeffs'][:, :B]), t(b['yaw_lo'][:B]), t(b['yaw_hi'][:B])
     mpc = pkg.BatchedMPC(params, B, device=0)
     outs = mpc.alloc_outputs(B, dev, want_traj=True)
     ks = []
-    for rep in range(6):
-        mpc.solve_torch(st, cf, yl, yh, outputs=outs); torch.cuda.synchronize()
+    for rep in range(int(os.environ.get('REPS', 6))):
+        mpc.solve_torch(st, cf, yl, yh, outputs=outs)
+        if not os.environ.get('NOSYNC'): torch.cuda.synchronize()
         s = mpc.stats(); ks.append(s.kernel_ms)
     k = float(np.median(ks[1:]))
     print('B %6d kernel %.3f ms  %.3g solves/s  ns/solve %.1f  iters mean %.2f max %d succ %d' % (B, k, B / k * 1e3, k * 1e6 / B, s.iter_sum / B, s.iter_max, s.n_success), flush=True)
