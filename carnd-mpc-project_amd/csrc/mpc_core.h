@@ -110,6 +110,7 @@ struct HostWorkspace {
   MPC_HD void stage_fetch_x(int, int, int) const {}
   MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
+  MPC_HD void stage_drain() const {}
   MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
   MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
 };
@@ -214,6 +215,15 @@ struct TiledWorkspace {
   MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0, 0); }
   MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F, STG_IT_OPS); }
   MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
+  /* Between sweeps: a sweep's first copies read what the sweep before it stored.  Vector memory operations of
+   * one wave are issued and performed in order, so a copy issued after a store to the same address returns the
+   * stored data without a wait in between (the same guarantee every ordinary store-then-load relies on);
+   * -DMPC_DRAIN restores the explicit wait for all earlier stores (A/B: identical results). */
+  MPC_HD void stage_drain() const {
+#if defined(MPC_DRAIN)
+    stage_wait<0>();
+#endif
+  }
   template <int N> MPC_HD void stage_wait() const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (STAGING) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -516,7 +526,7 @@ struct Solver {
     /* Staging: record j of the iterate (the fields of stage j) sits in buffer (M-1-j)&1.  Stage k needs
      * (u_k, lam_{k+1}, duals of u_k) from record k -- moved to registers one iteration earlier -- and
      * (s_k, delta_{k-1}, duals of s_k) from record k-1; record k-2 is requested meanwhile. */
-    ws.template stage_wait<0>();                     /* earlier stores of this wave have landed */
+    ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
     ws.template stage_wait<0>();
     double sn[6];                                    /* s_{k+1} */
@@ -724,7 +734,7 @@ struct Solver {
     double sk[6];
     load_state(0, I, sk);
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
-    ws.template stage_wait<0>();
+    ws.stage_drain();
     ws.stage_fetch_it(0, 0, I);
     ws.stage_fetch_x(0, 0, F_GK);
     for (int k = 0; k < M; ++k) {
@@ -819,7 +829,7 @@ struct Solver {
     double sn_t[6] = {0, 0, 0, 0, 0, 0}, ln_t[6] = {0, 0, 0, 0, 0, 0}, del_t = 0, acc_t = 0, del_nx = 0;
     double zdl_t = 0, zdu_t = 0, zal_t = 0, zau_t = 0;
     /* staging: record j (iterate + direction of stage j) in buffer (M-1-j)&1 */
-    ws.template stage_wait<0>();
+    ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
     ws.stage_fetch_d(0, M - 1);
     for (int k = M; k >= 0; --k) {
