@@ -238,8 +238,11 @@ struct TiledWorkspace {
 #endif
 
 /* ---- light-weight math (same code on device and in the test-only host build) ---- */
-/* reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the barrier terms need dozens of 1/slack
- * per stage and a full IEEE division costs ~3x as many instructions */
+/* reciprocal: v_rcp_f64 seed (measured on gfx950: 4.6e-8 relative, tools/rcp_test.hip) + Newton steps;
+ * a full IEEE division costs ~3x as many instructions and the barrier terms need dozens of 1/slack per stage.
+ *   frcp   two steps, 1.1e-16: where the quotient is a result (atan, log)
+ *   frcp1  one step,  2.2e-15: slack and pivot reciprocals, which only shape the Newton system (the
+ *          optimality error of a point is evaluated from the duals themselves, never from 1/slack) */
 MPC_HD double frcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
@@ -248,6 +251,15 @@ MPC_HD double frcp(double x) {
   e = fma(-x, r, 1.0);
   r = fma(r, e, r);
   return r;
+#else
+  return 1.0 / x;
+#endif
+}
+MPC_HD double frcp1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, e, r);
 #else
   return 1.0 / x;
 #endif
@@ -462,7 +474,7 @@ struct Solver {
     fsincos2(s[2], s[5], &L.sp, &L.cp, &L.se, &L.ce);
     double f, fp, fpp, fppp;
     poly(s[0], f, fp, fpp, fppp);
-    const double q1 = 1.0 + fp * fp, iq1 = frcp(q1);
+    const double q1 = 1.0 + fp * fp, iq1 = frcp1(q1);
     L.fp = fp;
     L.g1 = fpp * iq1;
     L.h3 = (fppp * q1 - 2.0 * fp * fpp * fpp) * (iq1 * iq1);
@@ -481,7 +493,7 @@ struct Solver {
   MPC_HD void state_terms(double psi, double v, double c, double e, double zlp, double zup, double zlv,
                           double zuv, double &Hpp, double &Hvv, double &Hee, double &Hcc, double &gp,
                           double &gv, double &ge, double &gc) const {
-    const double islp = frcp(psi - yl), isup = frcp(yu - psi), islv = frcp(v - vl), isuv = frcp(vu - v);
+    const double islp = frcp1(psi - yl), isup = frcp1(yu - psi), islv = frcp1(v - vl), isuv = frcp1(vu - v);
     const double mub = lsm ? 0.0 : mu;
     Hpp = lsm ? 1.0 : zlp * islp + zup * isup;
     Hvv = lsm ? 1.0 : df * 2.0 * wv + zlv * islv + zuv * isuv;
@@ -596,7 +608,7 @@ struct Solver {
       double qt[7];
       MPC_GT(t, tc, qt);
       /* the stage's own control terms */
-      const double isld = frcp(delta - dl), isud = frcp(du - delta), isla = frcp(acc - al), isua = frcp(au - acc);
+      const double isld = frcp1(delta - dl), isud = frcp1(du - delta), isla = frcp1(acc - al), isua = frcp1(au - acc);
       double ddl = 0, Hdd = 0;
       if (k >= 1 && !lsm) { ddl = delta - delprev; Hdd = df * 2.0 * wdd; }   /* LS start: all delta are 0 */
       const double mub = lsm ? 0.0 : mu;
@@ -618,7 +630,7 @@ struct Solver {
         const double Raa = o6[6] + Sga + dw;
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-        const double idet = frcp(det);
+        const double idet = frcp1(det);
         ws.store2(0, 0, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
         break;
       }
@@ -672,7 +684,7 @@ struct Solver {
       const double Raa = Mx[6][6] + Sga + dw;
       const double det = Rdd * Raa - Rda * Rda;
       if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-      const double idet = frcp(det);
+      const double idet = frcp1(det);
       const double i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
       /* S~ (2 x 6 over x,y,psi,v,e,d) */
       double Sd[6], Sa[6], Kd[6], Ka[6];
@@ -775,12 +787,12 @@ struct Solver {
       const double dx[4] = {q2, q3, qd, qa};
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
-        const double isl = frcp(xs[b] - lo[b]), isu = frcp(hi[b] - xs[b]);
+        const double isl = frcp1(xs[b] - lo[b]), isu = frcp1(hi[b] - xs[b]);
         const double zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
         rmax = fmax(rmax, fmax(-dx[b] * isl, dx[b] * isu));
         const double dzl = mu * isl - zl - zl * isl * dx[b];
         const double dzu = mu * isu - zu + zu * isu * dx[b];
-        rzmax = fmax(rzmax, fmax(-dzl * frcp(zl), -dzu * frcp(zu)));
+        rzmax = fmax(rzmax, fmax(-dzl * frcp1(zl), -dzu * frcp1(zu)));
         dphi += mu * (isu - isl) * dx[b];
       }
       /* objective part of the directional derivative */
@@ -913,13 +925,13 @@ struct Solver {
         double zln[4], zun[4], prod = 1.0;
         MPC_UNROLL
         for (int b = 0; b < 4; b++) {
-          const double islo = frcp(xo[b] - lo[b]), isuo = frcp(hi[b] - xo[b]);
+          const double islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
           const double zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
           const double dzl = mu * islo - zl - zl * islo * dxb[b];
           const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
           const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
           if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
-          const double isl = frcp(sl), isu = frcp(su);
+          const double isl = frcp1(sl), isu = frcp1(su);
           double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
           /* kappa_sigma safeguard, W&B eq. (16) */
           a = fmax(fmin(a, ksm * isl), ksi * isl);

@@ -246,3 +246,28 @@ def test_device_light_math(pkg):
     big = np.array([1e9, -4e12]); o = [np.zeros(2) for _ in range(5)]
     check(pkg.library().mpc_debug_math_ext(0, 2, big.ctypes.data, *[a.ctypes.data for a in o]), "mpc_debug_math_ext")
     assert np.isnan(o[0]).all() and np.isnan(o[1]).all()                                # flagged beyond |x| = 1e9
+
+
+def test_staged_and_plain_kernels_are_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """The LDS-DMA staged kernel (counted vmcnt waits, no drain between sweeps, inline-assembly copies) against the
+    variant with ordinary loads (MPC_STAGING=0, every wait placed by the compiler): same arithmetic, so any ordering
+    mistake in the hand-managed staging shows up as a bit difference."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    res = {}
+    old = os.environ.get("MPC_STAGING")
+    try:
+        for N, dt, B in ((10, 0.1, 12288 + 37), (25, 0.05, 2048)):
+            q = params.copy(); q.N = N; q.dt = dt
+            b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=77)
+            for stg in ("1", "0"):
+                os.environ["MPC_STAGING"] = stg
+                res[stg] = gpu_solve(pkg, q, b, torch_dev)
+            for key in ("out", "traj", "status", "iters"):
+                assert np.array_equal(res["1"][key], res["0"][key]), (N, key)
+            assert (res["1"]["status"] == 0).all()
+    finally:
+        if old is None:
+            os.environ.pop("MPC_STAGING", None)
+        else:
+            os.environ["MPC_STAGING"] = old
