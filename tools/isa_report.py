@@ -6,7 +6,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = tempfile.mkdtemp()
 s_path = os.path.join(d, "solver.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + ROOT + "/include",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-I" + ROOT + "/include",
                        "-I" + ROOT + "/carnd-mpc-project_amd/csrc", "--cuda-device-only", "-S", "-o", s_path,
                        ROOT + "/carnd-mpc-project_amd/csrc/mpc_solver.hip"] + os.environ.get("EXTRA", "").split(), stderr=subprocess.DEVNULL)
 txt = open(s_path).read()
