@@ -54,8 +54,10 @@
 #endif
 #if defined(__HIPCC__) || defined(__clang__)
 #define MPC_UNROLL _Pragma("unroll")
+#define MPC_STAGE_LOOP _Pragma("clang loop unroll(disable)")   /* one copy of a sweep's stage body: no unrolling, no peeling */
 #else
 #define MPC_UNROLL _Pragma("GCC unroll 8")
+#define MPC_STAGE_LOOP
 #endif
 
 namespace mpc {
@@ -571,6 +573,7 @@ struct Solver {
     double zld = ws.sit(0, M - 1, I, F_ZL + 2), zud = ws.sit(0, M - 1, I, F_ZU + 2);
     double zla = ws.sit(0, M - 1, I, F_ZL + 3), zua = ws.sit(0, M - 1, I, F_ZU + 3);
     if (M >= 2) ws.stage_fetch_it(1, M - 2, I);
+    MPC_STAGE_LOOP
     for (int k = M - 1; k >= 0; --k) {
       /* ---- inputs of stage k ---- */
       double sk[6];
@@ -766,6 +769,7 @@ struct Solver {
     ws.stage_drain();
     ws.stage_fetch_itf(0, 0, I);
     ws.stage_fetch_gk(0, 0);
+    MPC_STAGE_LOOP
     for (int k = 0; k < M; ++k) {
       const int bf = k & 1;
       if (k + 1 < M) {
@@ -863,6 +867,7 @@ struct Solver {
     ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
     ws.stage_fetch_d(0, M - 1);
+    MPC_STAGE_LOOP
     for (int k = M; k >= 0; --k) {
       const int bk = (M - k) & 1;                    /* buffer of record k-1 */
       double s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
