@@ -64,8 +64,7 @@ namespace mpc {
 
 /* ---- workspace layout ------------------------------------------------------ */
 /* A "field" is one double per instance.  Stage k (0..N-2) owns:
- *   two iterate slots: s_{k+1} (6), u_k (2), bound duals of (psi_{k+1}, v_{k+1}, delta_k, a_k) (4+4),
- *                      sin/cos of psi_{k+1} and epsi_{k+1} (4: computed once, when the point is formed), lam_{k+1} (6)
+ *   two iterate slots: s_{k+1} (6), u_k (2), lam_{k+1} (6), bound duals of (psi_{k+1}, v_{k+1}, delta_k, a_k) (4+4)
  *   the Newton direction  ds_{k+1} (6), du_k (2), dlam_{k+1} (6)
  *   the Riccati gains     K_k (2x6) and kff_k (2)   -- in LDS on the device when the launch allows it
  * Nothing else is kept: the stage model (sin/cos/atan, road polynomial, residual) is recomputed
@@ -74,7 +73,7 @@ namespace mpc {
  * absolute error of ~1e-8 in a step component is fatal next to slacks of ~1e-9 at active bounds
  * (+11 % iterations and a few non-converged instances on the 65 536-instance workload). */
 enum : int {
-  F_S = 0, F_U = 6, F_ZL = 8, F_ZU = 12, F_SC = 16, F_LAM = 20, IT_SZ = 26,   /* one iterate slot */
+  F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
   F_D = 2 * IT_SZ, D_N = 8,                                        /* direction (ds, du) */
   F_GK = F_D + D_N, GK_N = 12,                                     /* gains K (HBM placement) */
@@ -91,13 +90,11 @@ MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
 MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N + GF_N) * 8 * 64; }
 
 /* Staging interface (see TiledWorkspace): a sweep asks for the record of the NEXT stage while it works on the
- * current one.  stage_fetch_it copies the IT_SZ fields of an iterate slot of stage k to the front of buffer `buf`
- * and stage_fetch_d the direction behind it (read back with sit()/sx()); the forward sweep, which does not need the
- * multipliers, copies only the fields before F_LAM (stage_fetch_itf) and puts the gains there (stage_fetch_gk,
- * sxf()).  stage_wait<N>() waits until at most the N most recent copy/store instructions are still in flight.
- * On the host build all of this degenerates to direct reads. */
-enum : int { STG_IT_OPS = IT_SZ / 2, STG_ITF_OPS = F_LAM / 2, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = 18 };
-static_assert(STG_IT_OPS + STG_D_OPS <= STG_SLOT_PAIRS && STG_ITF_OPS + STG_X_OPS <= STG_SLOT_PAIRS, "LDS slot too small");
+ * current one.  stage_fetch_it copies the IT_SZ fields of an iterate slot of stage k to the front of buffer `buf`,
+ * stage_fetch_x / stage_fetch_d the gains or the direction behind it; sit()/sx() read them back; stage_wait<N>()
+ * waits until at most the N most recent copy/store instructions are still in flight.  On the host build all of
+ * this degenerates to direct reads. */
+enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
 /* pair stores a stage issues in each sweep (all through store2): the counted waits let exactly these
  * stay in flight besides the newest copy group */
 enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_TRIAL = IT_SZ / 2 };
@@ -111,14 +108,12 @@ struct HostWorkspace {
   MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_D + j] = v; }
   MPC_HD void store2(int k, int I, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + I + f] = a; base[k * STAGE_SZ_GLOBAL + I + f + 1] = b; }
   MPC_HD void stage_fetch_it(int, int, int) const {}
-  MPC_HD void stage_fetch_itf(int, int, int) const {}
-  MPC_HD void stage_fetch_gk(int, int) const {}
+  MPC_HD void stage_fetch_x(int, int, int) const {}
   MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
   MPC_HD void stage_drain() const {}
   MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
   MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
-  MPC_HD double sxf(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
 };
 
 #if defined(__HIPCC__)
@@ -219,16 +214,14 @@ struct TiledWorkspace {
 #endif
   }
   MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0, 0); }
-  /* forward sweep: the iterate without its multipliers (fields 0..F_LAM-1), the gains right behind it */
-  MPC_HD void stage_fetch_itf(int buf, int k, int I) const { if (STAGING) dma<STG_ITF_OPS>(buf, k, I, 0, 0); }
-  MPC_HD void stage_fetch_gk(int buf, int k) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F_GK, STG_ITF_OPS); }
+  MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F, STG_IT_OPS); }
   MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
-  /* Between sweeps: a sweep's first copies read what the sweep before it stored.  Vector memory operations of
-   * one wave are issued and performed in order, so a copy issued after a store to the same address returns the
-   * stored data without a wait in between (the same guarantee every ordinary store-then-load relies on);
-   * -DMPC_DRAIN restores the explicit wait for all earlier stores (A/B: identical results). */
+  /* Between sweeps: a sweep's first copies read what the sweep before it stored, so all earlier stores of the
+   * wave are waited for first.  (Vector memory operations of one wave are performed in order, and with
+   * -DMPC_NO_DRAIN the results stay bitwise identical; the wait costs nothing measurable -- same-box A/B 2.02 vs
+   * 2.04 ms at 65 536 instances -- so the explicit form is kept.) */
   MPC_HD void stage_drain() const {
-#if defined(MPC_DRAIN)
+#if !defined(MPC_NO_DRAIN)
     stage_wait<0>();
 #endif
   }
@@ -242,7 +235,6 @@ struct TiledWorkspace {
   }
   MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)it(k, I, j); }
   MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, 0, F + j); }
-  MPC_HD double sxf(int buf, int k, int F, int j) const { return STAGING ? sl(buf, F_LAM + j) : (double)it(k, 0, F + j); }
 };
 #endif
 
@@ -445,7 +437,6 @@ struct Solver {
   WS ws;
   /* instance data */
   double st[6], coef[MPC_NCOEF], yl, yu;
-  double sc0[4];   /* sin psi_0, cos psi_0, sin epsi_0, cos epsi_0 */
   double wc, we, wv, wd, wdd, vref, cost0;
   /* bounds */
   double vl, vu, dl, du, al, au;
@@ -482,11 +473,6 @@ struct Solver {
    * Recomputed wherever it is needed (see the layout comment). */
   MPC_HD void linearise(const double *s, double delta, double a, const double *sn, Lin &L) const {
     fsincos2(s[2], s[5], &L.sp, &L.cp, &L.se, &L.ce);
-    linearise_sc(s, delta, a, sn, L);
-  }
-  /* the same with sin/cos of (psi, epsi) already in L: every point's values are computed once, when the point is
-   * formed (trial part of the costate/trial sweep), stored with the iterate and read by the other sweeps */
-  MPC_HD void linearise_sc(const double *s, double delta, double a, const double *sn, Lin &L) const {
     double f, fp, fpp, fppp;
     poly(s[0], f, fp, fpp, fppp);
     const double q1 = 1.0 + fp * fp, iq1 = frcp1(q1);
@@ -578,7 +564,6 @@ struct Solver {
       /* ---- inputs of stage k ---- */
       double sk[6];
       double zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
-      Lin L;
       const int bk = (M - k) & 1;                    /* buffer of record k-1 */
       if (k > 0) {
         if (k >= 2) {
@@ -592,15 +577,13 @@ struct Solver {
         zlp = ws.sit(bk, k - 1, I, F_ZL + 0); zup = ws.sit(bk, k - 1, I, F_ZU + 0);
         zlv = ws.sit(bk, k - 1, I, F_ZL + 1); zuv = ws.sit(bk, k - 1, I, F_ZU + 1);
         delprev = ws.sit(bk, k - 1, I, F_U + 0);
-        L.sp = ws.sit(bk, k - 1, I, F_SC + 0); L.cp = ws.sit(bk, k - 1, I, F_SC + 1);
-        L.se = ws.sit(bk, k - 1, I, F_SC + 2); L.ce = ws.sit(bk, k - 1, I, F_SC + 3);
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = st[i];
-        L.sp = sc0[0]; L.cp = sc0[1]; L.se = sc0[2]; L.ce = sc0[3];
       }
       const double v = sk[3];
-      linearise_sc(sk, delta, acc, sn, L);
+      Lin L;
+      linearise(sk, delta, acc, sn, L);
       const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
       const double r0 = rsc * L.c[0], r1 = rsc * L.c[1], r2 = rsc * L.c[2], r3 = rsc * L.c[3], rc = rsc * L.c[4], r4 = rsc * L.c[5];
       const double vdt = v * dt;
@@ -764,19 +747,18 @@ struct Solver {
     dphi = 0.0; dxinf = 0.0; xinf = 0.0;
     double sk[6];
     load_state(0, I, sk);
-    double scp = sc0[0], ccp = sc0[1], sce = sc0[2], cce = sc0[3];   /* sin/cos of (psi_k, epsi_k) */
-    /* staging: stage k's iterate record (without multipliers) and gains in buffer k&1, stage k+1 requested meanwhile */
+    /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
-    ws.stage_fetch_itf(0, 0, I);
-    ws.stage_fetch_gk(0, 0);
+    ws.stage_fetch_it(0, 0, I);
+    ws.stage_fetch_x(0, 0, F_GK);
     MPC_STAGE_LOOP
     for (int k = 0; k < M; ++k) {
       const int bf = k & 1;
       if (k + 1 < M) {
-        ws.stage_fetch_itf(bf ^ 1, k + 1, I);
-        ws.stage_fetch_gk(bf ^ 1, k + 1);
-        if (k == 0) ws.template stage_wait<STG_ITF_OPS + STG_X_OPS>();
-        else ws.template stage_wait<STG_ITF_OPS + STG_X_OPS + ST_FORWARD>();
+        ws.stage_fetch_it(bf ^ 1, k + 1, I);
+        ws.stage_fetch_x(bf ^ 1, k + 1, F_GK);
+        if (k == 0) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
+        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_FORWARD>();
       } else ws.template stage_wait<0>();
       double sn[6];
       MPC_UNROLL
@@ -784,15 +766,13 @@ struct Solver {
       const double v = sk[3];
       const double delta = ws.sit(bf, k, I, F_U + 0), acc = ws.sit(bf, k, I, F_U + 1);
       Lin L;
-      L.sp = scp; L.cp = ccp; L.se = sce; L.ce = cce;
-      linearise_sc(sk, delta, acc, sn, L);
-      scp = ws.sit(bf, k, I, F_SC + 0); ccp = ws.sit(bf, k, I, F_SC + 1); sce = ws.sit(bf, k, I, F_SC + 2); cce = ws.sit(bf, k, I, F_SC + 3);
-      double dd = ws.sxf(bf, k, F_GK, GK_N + 0), da = ws.sxf(bf, k, F_GK, GK_N + 1);
+      linearise(sk, delta, acc, sn, L);
+      double dd = ws.sx(bf, k, F_GK, GK_N + 0), da = ws.sx(bf, k, F_GK, GK_N + 1);
       if (k > 0) {
-        dd += ws.sxf(bf, k, F_GK, 0) * d0 + ws.sxf(bf, k, F_GK, 1) * d1 + ws.sxf(bf, k, F_GK, 2) * d2 + ws.sxf(bf, k, F_GK, 3) * d3 +
-              ws.sxf(bf, k, F_GK, 4) * d5 + ws.sxf(bf, k, F_GK, 5) * ddprev;
-        da += ws.sxf(bf, k, F_GK, 6) * d0 + ws.sxf(bf, k, F_GK, 7) * d1 + ws.sxf(bf, k, F_GK, 8) * d2 + ws.sxf(bf, k, F_GK, 9) * d3 +
-              ws.sxf(bf, k, F_GK, 10) * d5 + ws.sxf(bf, k, F_GK, 11) * ddprev;
+        dd += ws.sx(bf, k, F_GK, 0) * d0 + ws.sx(bf, k, F_GK, 1) * d1 + ws.sx(bf, k, F_GK, 2) * d2 + ws.sx(bf, k, F_GK, 3) * d3 +
+              ws.sx(bf, k, F_GK, 4) * d5 + ws.sx(bf, k, F_GK, 5) * ddprev;
+        da += ws.sx(bf, k, F_GK, 6) * d0 + ws.sx(bf, k, F_GK, 7) * d1 + ws.sx(bf, k, F_GK, 8) * d2 + ws.sx(bf, k, F_GK, 9) * d3 +
+              ws.sx(bf, k, F_GK, 10) * d5 + ws.sx(bf, k, F_GK, 11) * ddprev;
       }
       const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const double n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
@@ -908,9 +888,7 @@ struct Solver {
           } else {
             const double v = s_o[3];
             Lin L;
-            L.sp = ws.sit(bk, r, I, F_SC + 0); L.cp = ws.sit(bk, r, I, F_SC + 1);
-            L.se = ws.sit(bk, r, I, F_SC + 2); L.ce = ws.sit(bk, r, I, F_SC + 3);
-            linearise_sc(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
+            linearise(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
             const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
             const double vdt = v * dt, Apv = del_o * dtLf;
             /* curvature of stage k */
@@ -983,11 +961,7 @@ struct Solver {
       if (k < M) {
         /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
         Lin L;
-        if (k >= 1) {
-          fsincos2(s_t[2], s_t[5], &L.sp, &L.cp, &L.se, &L.ce);
-          ws.store2(k - 1, J, F_SC + 0, L.sp, L.cp); ws.store2(k - 1, J, F_SC + 2, L.se, L.ce);
-        } else { L.sp = sc0[0]; L.cp = sc0[1]; L.se = sc0[2]; L.ce = sc0[3]; }
-        linearise_sc(s_t, del_t, acc_t, sn_t, L);
+        linearise(s_t, del_t, acc_t, sn_t, L);
         MPC_UNROLL
         for (int i = 0; i < 6; i++) { R.theta += fabs(L.c[i]); R.cinf = fmax(R.cinf, fabs(L.c[i])); }
         const double ddl = (k >= 1) ? del_t - n_del_t : 0.0;          /* delta_k - delta_{k-1} */
@@ -1011,9 +985,6 @@ struct Solver {
           R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
         }
       } else {
-        /* s_M starts no transition: its sin/cos slots are never read, but every step issues the same number of
-         * stores (the counted waits rely on it) */
-        ws.store2(k - 1, J, F_SC + 0, 0.0, 0.0); ws.store2(k - 1, J, F_SC + 2, 0.0, 0.0);
         /* terminal state rows */
         const double r2 = lam_t[2] - zs0 + zs1;
         const double r3 = df * 2.0 * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
@@ -1088,7 +1059,6 @@ struct Solver {
     for (int i = 0; i < MPC_NCOEF; i++) coef[i] = coef5[i];
     yl = yaw_lo; yu = yaw_hi;
     M = P.N - 1; dt = P.dt; iLf = 1.0 / P.Lf; dtLf = P.dt / P.Lf;
-    fsincos2(st[2], st[5], &sc0[0], &sc0[1], &sc0[2], &sc0[3]);
     vl = -P.max_speed; vu = P.max_speed; dl = -P.max_steering; du = P.max_steering;
     al = P.max_deceleration; au = P.max_acceleration;
     fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = 0.0;
