@@ -94,7 +94,7 @@ MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N
  * stage_fetch_x / stage_fetch_d the gains or the direction behind it; sit()/sx() read them back; stage_wait<N>()
  * waits until at most the N most recent copy/store instructions are still in flight.  On the host build all of
  * this degenerates to direct reads. */
-enum : int { STG_IT_OPS = IT_SZ / 2, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
+enum : int { STG_IT_OPS = IT_SZ / 2, STG_ITF_OPS = 8, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
 /* pair stores a stage issues in each sweep (all through store2): the counted waits let exactly these
  * stay in flight besides the newest copy group */
 enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_TRIAL = IT_SZ / 2 };
@@ -108,6 +108,7 @@ struct HostWorkspace {
   MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_D + j] = v; }
   MPC_HD void store2(int k, int I, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + I + f] = a; base[k * STAGE_SZ_GLOBAL + I + f + 1] = b; }
   MPC_HD void stage_fetch_it(int, int, int) const {}
+  MPC_HD void stage_fetch_itf(int, int, int) const {}
   MPC_HD void stage_fetch_x(int, int, int) const {}
   MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
@@ -214,6 +215,10 @@ struct TiledWorkspace {
 #endif
   }
   MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0, 0); }
+  /* the forward sweep does not read the multipliers: (s, u) and the bound duals go to their usual places */
+  MPC_HD void stage_fetch_itf(int buf, int k, int I) const {
+    if (STAGING) { dma<4>(buf, k, I, F_S, F_S / 2); dma<4>(buf, k, I, F_ZL, F_ZL / 2); }
+  }
   MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F, STG_IT_OPS); }
   MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
   /* Between sweeps: a sweep's first copies read what the sweep before it stored, so all earlier stores of the
@@ -749,16 +754,16 @@ struct Solver {
     load_state(0, I, sk);
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
-    ws.stage_fetch_it(0, 0, I);
+    ws.stage_fetch_itf(0, 0, I);
     ws.stage_fetch_x(0, 0, F_GK);
     MPC_STAGE_LOOP
     for (int k = 0; k < M; ++k) {
       const int bf = k & 1;
       if (k + 1 < M) {
-        ws.stage_fetch_it(bf ^ 1, k + 1, I);
+        ws.stage_fetch_itf(bf ^ 1, k + 1, I);
         ws.stage_fetch_x(bf ^ 1, k + 1, F_GK);
-        if (k == 0) ws.template stage_wait<STG_IT_OPS + STG_X_OPS>();
-        else ws.template stage_wait<STG_IT_OPS + STG_X_OPS + ST_FORWARD>();
+        if (k == 0) ws.template stage_wait<STG_ITF_OPS + STG_X_OPS>();
+        else ws.template stage_wait<STG_ITF_OPS + STG_X_OPS + ST_FORWARD>();
       } else ws.template stage_wait<0>();
       double sn[6];
       MPC_UNROLL
