@@ -82,6 +82,13 @@ def library():
     path = library_path()
     if not os.path.exists(path):
         raise MpcError("HIP extension %s is missing: run __graft_entry__.build() (there is no CPU fallback)" % path)
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64 (same soname as /opt/rocm's).  If this
+    # library were loaded first it would bind /opt/rocm's copy, and torch, imported later, would then fail to see a
+    # device.  Importing torch first makes both use the copy torch ships.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     DP = C.c_void_p
     L.mpc_params_default.argtypes = [C.POINTER(MpcParams)]
