@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-process path on a single GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,7 +96,10 @@ def main():
     w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank) if args.weights_sweep else None
     d_w = t(w_np) if w_np is not None else None
     mpc = pkg.BatchedMPC(params, B, device=local_rank)
-    outs = mpc.alloc_outputs(B, dev, want_traj)
+    # results go straight into a packed buffer that is gathered with one all_gather_into_tensor; two buffer sets
+    # alternate so that the gather of batch i overlaps the solve of batch i+1 (sharding.PackedGather)
+    pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap)
+    outs = pg.outputs(0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -103,27 +107,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    gathered = None
+    nstep = 0
 
-    def step():
-        nonlocal gathered
-        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=outs)   # async on torch's current stream
-        if dist is not None:
-            gathered = pkg.sharding.gather_results(outs, B * world, dist)  # the path's only collective
+    def step(ev=None):
+        nonlocal nstep
+        slot = nstep & 1
+        pg.wait(slot)                                   # the gather that last read this buffer set has finished
+        if ev is not None:
+            ev[0].record()
+        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(slot))   # async, torch's current stream
+        if ev is not None:
+            ev[1].record()
+        pg.start(slot)                                  # the path's only collective
+        nstep += 1
 
     for _ in range(args.warmup):
         step()
+    pg.finish()
     sync_all()
     # HIP events on the stream the kernel is launched on: torch's current stream, whose handle is what
     # solve_torch passes to mpc_solve_batch_device (a NULL handle is HIP's null stream = torch's default)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=outs)
-        ev[i][1].record()
-        if dist is not None:
-            gathered = pkg.sharding.gather_results(outs, B * world, dist)
+        step(ev[i])
+    pg.finish()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -133,8 +141,14 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms_avg = float(np.mean(kernel_ms))
     stats = mpc.stats()
+    last = (nstep - 1) & 1
+    outs = pg.outputs(last)
     status = outs["status"].cpu().numpy()
     out_np = outs["out"].cpu().numpy()
+    # the gathered copy of this rank's shard must be what the solver wrote
+    g = pg.result(last)
+    gather_ok = bool(torch.equal(g["out"][rank if dist is not None else 0], outs["out"]) and
+                     torch.equal(g["status"][rank if dist is not None else 0], outs["status"]))
 
     if rank != 0:
         mpc.close()
@@ -156,7 +170,9 @@ def main():
                                   B, params.N, params.dt, args.config, "on" if want_traj else "off",
                                   ", per-instance weight sweep" if args.weights_sweep else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
-                   "parallelism": "%d independent shard(s), one all_gather of results" % world,
+                   "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch%s"
+                                  % (world, ", overlapped with the next batch's solve" if (pg.overlap) else ""),
+                   "gather_checked": gather_ok,
                    "branch_mode": "frozen", "tol": params.tol, "max_iter": params.max_iter},
         "converged_fraction": float((status == 0).mean()),
         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},

@@ -70,3 +70,80 @@ def gather_results(local, B, dist=None, group=None):
         res["traj"] = None
     res["status"] = full[ofs].to(torch.int32); res["iters"] = full[ofs + 1].to(torch.int32)
     return res
+
+
+class PackedGather:
+    """Zero-copy gather for equal shards (the weak-scaling bench, and any batch divisible by the world size).
+
+    The solver writes its results straight into one packed float64 buffer per rank,
+        rows 0..8 out | 9..9+2N-1 trajectory (optional) | last row: status and iters as 2 x int32 per instance,
+    which is then gathered with ONE all_gather_into_tensor into full[rank, row, instance]: no packing kernels, no
+    re-layout.  Two buffer sets alternate (slot = step & 1), and with overlap=True the collective is issued
+    asynchronously: the gather of batch i runs while batch i+1 is being solved (its workgroups fit into the SIMDs
+    that the solve frees in its tail), and a slot is reused only after its gather has completed.
+    """
+
+    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True):
+        import torch
+        if dist is None:
+            import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.ws = dist.get_world_size(group) if self.active else 1
+        self.b, self.N, self.want_traj = int(b), int(N), bool(want_traj)
+        self.rows = 9 + (2 * self.N if want_traj else 0) + 1
+        self.nccl = self.active and dist.get_backend(group) == "nccl"
+        self.overlap = bool(overlap) and self.nccl
+        self.pack = [torch.zeros((self.rows, self.b), dtype=torch.float64, device=device) for _ in range(2)]
+        self.full = [torch.zeros((self.ws, self.rows, self.b), dtype=torch.float64, device=device) for _ in range(2)] \
+            if self.active else [None, None]
+        self.work = [None, None]
+
+    def outputs(self, slot):
+        """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffer of `slot`."""
+        p = self.pack[slot]
+        ints = p[self.rows - 1].view(self.torch.int32)            # 2*b int32 in the last row
+        return {"out": p[0:9], "traj": p[9:9 + 2 * self.N] if self.want_traj else None,
+                "status": ints[:self.b], "iters": ints[self.b:2 * self.b]}
+
+    def wait(self, slot):
+        """Make the current stream wait for the gather that last used `slot` (before the slot is written again)."""
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+
+    def start(self, slot):
+        """Gather the packed buffer of `slot` (call after the solve that filled it has been enqueued)."""
+        if not self.active:
+            return
+        dist, torch = self.dist, self.torch
+        if self.nccl:
+            try:
+                w = dist.all_gather_into_tensor(self.full[slot], self.pack[slot], group=self.group, async_op=self.overlap)
+            except RuntimeError:
+                if not self.overlap:
+                    raise
+                self.overlap = False                      # fall back to the synchronous collective
+                w = dist.all_gather_into_tensor(self.full[slot], self.pack[slot], group=self.group, async_op=False)
+            self.work[slot] = w if self.overlap else None
+        else:   # gloo (CPU tests, single-GPU rehearsal): through host memory, synchronous
+            src = self.pack[slot]
+            h = src.cpu() if src.is_cuda else src
+            parts = [torch.empty_like(h) for _ in range(self.ws)]
+            dist.all_gather(parts, h, group=self.group)
+            self.full[slot].copy_(torch.stack(parts, dim=0))
+
+    def finish(self):
+        for s in (0, 1):
+            self.wait(s)
+
+    def result(self, slot):
+        """Views of the gathered batch: out [ws,9,b], traj [ws,2N,b] or None, status/iters [ws,b] (int32)."""
+        if not self.active:
+            o = self.outputs(slot)
+            return {k: (v[None] if v is not None else None) for k, v in o.items()}
+        f = self.full[slot]
+        ints = f[:, self.rows - 1].contiguous().view(self.torch.int32).reshape(self.ws, 2 * self.b)
+        return {"out": f[:, 0:9], "traj": f[:, 9:9 + 2 * self.N] if self.want_traj else None,
+                "status": ints[:, :self.b], "iters": ints[:, self.b:]}

@@ -62,3 +62,63 @@ def test_two_rank_shard_solve_gather(host_twin, B):
         assert p.exitcode == 0
     assert all(same.values()), same
     assert cut == (0, (B + 1) // 2)
+
+
+def _worker_packed(rank, world, port, b, q):
+    """PackedGather (the bench's zero-copy gather) on CPU tensors over gloo: two alternating buffer sets."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as G
+    pkg = G.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 10
+    pg = pkg.sharding.PackedGather(b, N, True, torch.device("cpu"))
+    ok = pg.active and pg.ws == world and not pg.overlap          # overlap needs RCCL
+    for step in range(3):
+        slot = step & 1
+        pg.wait(slot)
+        o = pg.outputs(slot)
+        # what a solve would write: values that identify (rank, step, row, instance)
+        o["out"].copy_(torch.arange(9 * b, dtype=torch.float64).reshape(9, b) + 1000.0 * rank + 1e5 * step)
+        o["traj"].copy_(torch.arange(2 * N * b, dtype=torch.float64).reshape(2 * N, b) - 7.0 * rank)
+        o["status"].copy_(torch.full((b,), rank, dtype=torch.int32))
+        o["iters"].copy_(torch.arange(b, dtype=torch.int32) + 100 * step)
+        pg.start(slot)
+    pg.finish()
+    r = pg.result(2 & 1)
+    for rr in range(world):
+        ok = ok and torch.equal(r["out"][rr], torch.arange(9 * b, dtype=torch.float64).reshape(9, b) + 1000.0 * rr + 2e5)
+        ok = ok and torch.equal(r["traj"][rr], torch.arange(2 * N * b, dtype=torch.float64).reshape(2 * N, b) - 7.0 * rr)
+        ok = ok and torch.equal(r["status"][rr], torch.full((b,), rr, dtype=torch.int32))
+        ok = ok and torch.equal(r["iters"][rr], torch.arange(b, dtype=torch.int32) + 200)
+    r1 = pg.result(1)                                              # the other buffer set still holds step 1
+    ok = ok and torch.equal(r1["iters"][1 - rank], torch.arange(b, dtype=torch.int32) + 100)
+    dist.barrier()
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_packed_gather_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 7
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, 48, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+def test_packed_gather_single_process(pkg):
+    pg = pkg.sharding.PackedGather(16, 10, False, torch.device("cpu"))
+    assert not pg.active
+    o = pg.outputs(0)
+    assert o["traj"] is None and o["out"].shape == (9, 16) and o["status"].dtype == torch.int32
+    o["out"].fill_(3.0); o["status"].fill_(2); o["iters"].fill_(11)
+    pg.start(0); pg.finish()
+    r = pg.result(0)
+    assert r["out"].shape == (1, 9, 16) and float(r["out"].sum()) == 3.0 * 9 * 16
+    assert int(r["status"].sum()) == 32 and int(r["iters"].sum()) == 176
