@@ -50,6 +50,7 @@ def main():
                     "rehearse the multi-process path on a single GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
+    ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,6 +122,12 @@ def main():
         pg.start(slot)                                  # the path's only collective
         nstep += 1
 
+    # The solves run on a high-priority stream: when a batch's gather (RCCL's own stream, normal priority) and the next
+    # batch's solve become ready together, the solve's 1 024 waves are placed first and the collective's workgroups take
+    # the SIMDs the solve frees in its tail, instead of holding SIMDs that 512-register waves cannot share.
+    torch.cuda.synchronize(dev)
+    solve_stream = torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1)
+    torch.cuda.set_stream(solve_stream)
     for _ in range(args.warmup):
         step()
     pg.finish()
