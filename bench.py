@@ -8,13 +8,18 @@ A "step" is one pass of the hot path (the batched replacement of MPC::solve(), s
 over one batch of synthetic inputs that are ALREADY RESIDENT IN HBM.  Workload at every N: BASELINE.json
 configs[2] per GPU -- 65 536 lake-track states with 100 ms latency compensation, N=10, dt=0.1,
 config-fast.json, fp64, trajectories requested -- i.e. weak scaling: each rank solves its own 65 536
-instances (different PRNG streams), then the per-instance results are gathered once with a single
-all_gather (RCCL) inside the timed step.  Rank 0 prints ONE JSON line.
+instances (different PRNG streams), and every batch's per-instance results are gathered with a single
+all_gather_into_tensor (RCCL) inside the timed region.  Rank 0 prints ONE JSON line.
+
+Steps are pipelined the way a serving loop would run them: `--inflight` (default 2) handles on separate streams,
+so the next batch's waves take the SIMDs that the previous launch frees in its tail, and the gather of batch i
+overlaps the solve of batch i+1 (sharding.PackedGather).  All K steps, solves and gathers, complete inside the
+timed region (barrier + synchronize on both sides).
 
 roofline: bound "hbm" with ALGORITHMIC bytes = 336 B/solve (in 104 + out 72 +
 trajectory 160) x solves per launch / the solve kernel's average launch duration measured live with HIP
 events on the launch stream.  The path is fp64-VALU/latency bound, so the HBM fraction is tiny by
-construction; `fp64_valu_frac` next to it prices the same launches against the 78.6 TFLOP/s vector peak
+construction; `fp64_valu_frac` next to it prices the timed region against the 78.6 TFLOP/s vector peak
 using the algorithmic flop count of section 8d (2.5 kflop x stages x iterations).
 cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port"), one thread, a bounded sample of the same batch.
 """
@@ -49,6 +54,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-process path on a single GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (handles on separate streams)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     args = ap.parse_args()
@@ -96,10 +102,16 @@ def main():
     d_state, d_coef, d_ylo, d_yhi = t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"])
     w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank) if args.weights_sweep else None
     d_w = t(w_np) if w_np is not None else None
-    mpc = pkg.BatchedMPC(params, B, device=local_rank)
+    # Batches in flight: a launch of 65 536 instances is exactly one wave per SIMD and lasts as long as its slowest wave
+    # (25 iterations) while the average wave is done after ~70 % of that time; a second handle on a second stream lets
+    # the next batch's waves take the SIMDs as they become free (measured: 2.2 -> 1.5 ms per batch).
+    nfl = max(1, args.inflight)
+    mpcs = [pkg.BatchedMPC(params, B, device=local_rank) for _ in range(nfl)]
+    mpc = mpcs[0]
     # results go straight into a packed buffer that is gathered with one all_gather_into_tensor; two buffer sets
     # alternate so that the gather of batch i overlaps the solve of batch i+1 (sharding.PackedGather)
-    pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap)
+    pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
+                                   slots=max(2, nfl))
     outs = pg.outputs(0)
 
     def sync_all():
@@ -112,22 +124,23 @@ def main():
 
     def step(ev=None):
         nonlocal nstep
-        slot = nstep & 1
-        pg.wait(slot)                                   # the gather that last read this buffer set has finished
-        if ev is not None:
-            ev[0].record()
-        mpc.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(slot))   # async, torch's current stream
-        if ev is not None:
-            ev[1].record()
-        pg.start(slot)                                  # the path's only collective
+        slot = nstep % pg.slots
+        h = mpcs[nstep % nfl]
+        with torch.cuda.stream(streams[nstep % nfl]):
+            pg.wait(slot)                               # the gather that last read this buffer set has finished
+            if ev is not None:
+                ev[0].record()
+            h.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(slot))   # async on this stream
+            if ev is not None:
+                ev[1].record()
+            pg.start(slot)                              # the path's only collective
         nstep += 1
 
     # The solves run on a high-priority stream: when a batch's gather (RCCL's own stream, normal priority) and the next
     # batch's solve become ready together, the solve's 1 024 waves are placed first and the collective's workgroups take
     # the SIMDs the solve frees in its tail, instead of holding SIMDs that 512-register waves cannot share.
     torch.cuda.synchronize(dev)
-    solve_stream = torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1)
-    torch.cuda.set_stream(solve_stream)
+    streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(nfl)]
     for _ in range(args.warmup):
         step()
     pg.finish()
@@ -147,8 +160,16 @@ def main():
         elapsed = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms_avg = float(np.mean(kernel_ms))
-    stats = mpc.stats()
-    last = (nstep - 1) & 1
+    stats = mpcs[(nstep - 1) % nfl].stats()
+    last = (nstep - 1) % pg.slots
+    # the same launch alone on the device (nothing else in flight), for reference
+    iso = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(streams[0]):
+            e0.record(); mpcs[0].solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(0)); e1.record()
+        torch.cuda.synchronize(dev)
+        iso.append(e0.elapsed_time(e1))
     outs = pg.outputs(last)
     status = outs["status"].cpu().numpy()
     out_np = outs["out"].cpu().numpy()
@@ -158,7 +179,8 @@ def main():
                      torch.equal(g["status"][rank if dist is not None else 0], outs["status"]))
 
     if rank != 0:
-        mpc.close()
+        for h in mpcs:
+            h.close()
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -179,7 +201,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
                    "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch%s"
                                   % (world, ", overlapped with the next batch's solve" if (pg.overlap) else ""),
-                   "gather_checked": gather_ok,
+                   "gather_checked": gather_ok, "batches_in_flight": nfl,
                    "branch_mode": "frozen", "tol": params.tol, "max_iter": params.max_iter},
         "converged_fraction": float((status == 0).mean()),
         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
@@ -200,10 +222,15 @@ def main():
     res["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                        "kernel": "mpc_solve_kernel", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
+                       "kernel_ms_alone": float(np.median(iso)),
                        "algorithmic_bytes_per_launch": algo_bytes,
-                       "note": "fp64-VALU/latency-bound path: HBM fraction is small by construction (SURVEY.md 8d)",
-                       "fp64_valu_tflops": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (kernel_ms_avg * 1e-3) / 1e12,
-                       "fp64_valu_frac": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (kernel_ms_avg * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+                       "note": "fp64-VALU/latency-bound path: HBM fraction is small by construction (SURVEY.md 8d); "
+                               "kernel_ms_avg is the duration of a launch that shares the device with the other batch in flight, "
+                               "kernel_ms_alone the same launch by itself",
+                       # whole-device rate of this rank: with several batches in flight a launch shares the SIMDs, so the
+                       # flop rate is taken over the timed region, not over one launch's duration
+                       "fp64_valu_tflops": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (elapsed / args.steps) / 1e12,
+                       "fp64_valu_frac": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (elapsed / args.steps) / 1e12 / FP64_VALU_PEAK_TFLOPS}
 
     if world == 1 and not args.no_cpu_baseline:
         # the checker, timed as the CPU baseline: oracle = plain-C restatement of the reference algorithm
@@ -232,7 +259,8 @@ def main():
         res["max_abs_daccel_vs_oracle"] = worst_acc
         res["parity_sample"] = n_done
     print(json.dumps(res))
-    mpc.close()
+    for h in mpcs:
+        h.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

@@ -78,12 +78,12 @@ class PackedGather:
     The solver writes its results straight into one packed float64 buffer per rank,
         rows 0..8 out | 9..9+2N-1 trajectory (optional) | last row: status and iters as 2 x int32 per instance,
     which is then gathered with ONE all_gather_into_tensor into full[rank, row, instance]: no packing kernels, no
-    re-layout.  Two buffer sets alternate (slot = step & 1), and with overlap=True the collective is issued
+    re-layout.  `slots` buffer sets alternate (slot = step % slots), and with overlap=True the collective is issued
     asynchronously: the gather of batch i runs while batch i+1 is being solved (its workgroups fit into the SIMDs
     that the solve frees in its tail), and a slot is reused only after its gather has completed.
     """
 
-    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True):
+    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -94,10 +94,11 @@ class PackedGather:
         self.rows = 9 + (2 * self.N if want_traj else 0) + 1
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self.overlap = bool(overlap) and self.nccl
-        self.pack = [torch.zeros((self.rows, self.b), dtype=torch.float64, device=device) for _ in range(2)]
-        self.full = [torch.zeros((self.ws, self.rows, self.b), dtype=torch.float64, device=device) for _ in range(2)] \
-            if self.active else [None, None]
-        self.work = [None, None]
+        self.slots = int(slots)
+        self.pack = [torch.zeros((self.rows, self.b), dtype=torch.float64, device=device) for _ in range(self.slots)]
+        self.full = [torch.zeros((self.ws, self.rows, self.b), dtype=torch.float64, device=device) for _ in range(self.slots)] \
+            if self.active else [None] * self.slots
+        self.work = [None] * self.slots
 
     def outputs(self, slot):
         """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffer of `slot`."""
@@ -135,7 +136,7 @@ class PackedGather:
             self.full[slot].copy_(torch.stack(parts, dim=0))
 
     def finish(self):
-        for s in (0, 1):
+        for s in range(self.slots):
             self.wait(s)
 
     def result(self, slot):
