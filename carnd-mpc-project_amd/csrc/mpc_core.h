@@ -1107,136 +1107,151 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   /* the interior-point iteration                                         */
   /* ------------------------------------------------------------------ */
+  enum { MPC_RUNNING = -1 };
+  enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
+  /* state of the interior-point loop (see step()) */
+  int phase, iter;
+  bool ls_start, tiny;
+  double alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
+  double theta_k, phi_k, pth, pdp, amin;   /* line-search state */
+
+  /* Solve from the start point that setup()/start_point() has written.
+   * A line search that runs out of step length is where IPOPT would enter its feasibility-restoration phase.
+   * Stand-in (same as the oracle's): restart ONCE from the start point with zero equality multipliers. */
   MPC_HD int solve() {
-    int status = MPC_STATUS_LINESEARCH, it_total = 0;
-    /* A line search that runs out of step length is where IPOPT would enter its feasibility-
-     * restoration phase.  Stand-in (same as the oracle's): restart ONCE from the start point with
-     * zero equality multipliers.  (Written as a loop so that the solver body is instantiated once.) */
-    for (int attempt = 0; attempt < 2 && status == MPC_STATUS_LINESEARCH; ++attempt) {
-      if (attempt > 0) start_point();
-      status = solve_from_start(attempt == 0);
-      it_total += iters;
+    int it_total = 0, attempt = 0;
+    begin(true);
+    for (;;) {
+      const int r = step();
+      if (r == MPC_RUNNING) continue;
+      if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        attempt = 1; it_total += iters;
+        start_point();
+        begin(false);
+        continue;
+      }
+      iters += it_total;
+      return r;
     }
-    iters = it_total;
-    return status;
   }
 
-  /* The interior-point loop, written as a small state machine so that each of the four sweeps has
-   * exactly ONE call site (they are force-inlined; several call sites would multiply the code size
-   * and thrash the instruction cache):
-   *   EVAL0     evaluate the start point                       -> trial(0, 0)
+  MPC_HD void begin(bool ls) {
+    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
+    phase = PH_EVAL0; iter = 0; ls_start = ls; tiny = false;
+    alpha = alpha_l = alpha_z = dw_cur = 0.0;
+    theta_max = theta_min = dw_last = 0.0;
+    theta_k = phi_k = pth = pdp = amin = 0.0;
+  }
+
+  /* One pass of the interior-point loop, written as a small state machine so that each sweep has exactly ONE
+   * call site (they are force-inlined; several call sites would multiply the code size), and so that the lanes of
+   * a wave can be in different phases -- or, in the device kernel, on different instances:
+   *   EVAL0     evaluate the start point
    *   LS        least-squares multiplier start (W&B section 3.6, IPOPT default): one Riccati pass
    *             with identity Hessian; estimates above constr_mult_init_max = 1000 are discarded
    *   DIR       convergence test, barrier update, search direction, first trial of the line search
-   *   BACKTRACK further trials of the same line search                                              */
-  MPC_HD int solve_from_start(bool ls_start) {
-    enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
-    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
-    int phase = PH_EVAL0, iter = 0;
-    double alpha = 0.0, alpha_l = 0.0, alpha_z = 0.0, dw_cur = 0.0;
-    double theta_max = 0.0, theta_min = 0.0, dw_last = 0.0;
-    double theta_k = 0.0, phi_k = 0.0, pth = 0.0, pdp = 0.0, amin = 0.0;   /* line-search state */
-    bool tiny = false;
+   *   BACKTRACK further trials of the same line search
+   * Returns MPC_RUNNING, or the final status of this attempt. */
+  MPC_HD int step() {
     const double mu_floor = P.tol / 10.0;
-    for (;;) {
-      if (phase == PH_LS || phase == PH_DIR) {
-        if (phase == PH_DIR) {
-          iters = iter;
-          const double E0 = kkt_error(E, 0.0);
-          if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
-          if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
-          if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
-          /* barrier update, W&B eq. (7) */
-          while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
-            mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
-            tau = fmax(IpmConst::tau_min, 1.0 - mu);
-            nf = 0;
-          }
+    if (phase == PH_LS || phase == PH_DIR) {
+      if (phase == PH_DIR) {
+        iters = iter;
+        const double E0 = kkt_error(E, 0.0);
+        if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
+        if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
+        if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
+        /* barrier update, W&B eq. (7) */
+        while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
+          mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
+          tau = fmax(IpmConst::tau_min, 1.0 - mu);
+          nf = 0;
+        }
 #if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-          printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
-                 E.dinf, E.cmin, E.cmax, mu, E0, nf);
+        printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
+               E.dinf, E.cmin, E.cmax, mu, E0, nf);
 #endif
-        }
-        lsm = (phase == PH_LS);
-        /* search direction with inertia correction, W&B section 3.1 */
-        double dw = 0.0;
-        int tries = 0;
-        bool okb = true;
-        while (!backward(dw)) {
-          if (lsm) { okb = false; break; }
-          if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
-          else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
-          if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
-        }
-        if (okb) forward();
-        dw_cur = dw;
-        if (phase == PH_LS) {
-          if (!okb) { lsm = false; phase = PH_DIR; continue; }
-          alpha = 0.0; alpha_l = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
-        } else {
-          if (dw > 0.0) { dw_last = dw; n_reg++; }
-          /* filter line search, W&B algorithm A */
-          theta_k = E.theta; phi_k = df * E.f - mu * E.L;
-          pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
-          pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
-          if (dphi < 0.0) {
-            const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
-            amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
-          } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
-          tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
-          alpha = amax; alpha_l = amax; alpha_z = az;
-        }
       }
-      double lmax;
-      const Eval T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
-      if (phase == PH_EVAL0) {
-        E = T; cur = 1;
-        if (!E.ok) return MPC_STATUS_NUMERIC;
-        theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
-        phase = ls_start ? PH_LS : PH_DIR;
-        continue;
+      lsm = (phase == PH_LS);
+      /* search direction with inertia correction, W&B section 3.1 */
+      double dw = 0.0;
+      int tries = 0;
+      bool okb = true;
+      while (!backward(dw)) {
+        if (lsm) { okb = false; break; }
+        if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
+        else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
+        if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
       }
+      if (okb) forward();
+      dw_cur = dw;
       if (phase == PH_LS) {
-        lsm = false;
-        phase = PH_DIR;
-        /* estimates above constr_mult_init_max = 1000 are discarded (the iterate stays as it is) */
-        if (lmax <= 1000.0) {
-          E = T; cur = 1 - cur;
-          if (!E.ok) return MPC_STATUS_NUMERIC;
-        }
-        continue;
+        if (!okb) { lsm = false; phase = PH_DIR; return MPC_RUNNING; }
+        alpha = 0.0; alpha_l = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
+      } else {
+        if (dw > 0.0) { dw_last = dw; n_reg++; }
+        /* filter line search, W&B algorithm A */
+        theta_k = E.theta; phi_k = df * E.f - mu * E.L;
+        pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
+        pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
+        if (dphi < 0.0) {
+          const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
+          amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
+        } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
+        tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
+        alpha = amax; alpha_l = amax; alpha_z = az;
       }
-      /* acceptance test of the line search */
-      bool accepted = false, ftype = false;
-      if (tiny) { accepted = T.ok; ftype = true; }
-      else if (T.ok) {
-        const double phi_t = df * T.f - mu * T.L;
-        const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
-        if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
-          const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
-          const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
-          if (theta_k <= theta_min && sw) {
-            if (armijo) accepted = true;
-          } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
-                     phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
-            accepted = true;
-          }
-          ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
-        }
-      }
-      if (accepted) {
-        if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
-        cur = 1 - cur;
-        E = T;
-        ++iter;
-        phase = PH_DIR;
-        continue;
-      }
-      if (tiny) return MPC_STATUS_LINESEARCH;
-      alpha *= 0.5; alpha_l = alpha;
-      if (alpha < amin) return MPC_STATUS_LINESEARCH;
-      phase = PH_BACKTRACK;
     }
+    double lmax;
+    const Eval T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
+    if (phase == PH_EVAL0) {
+      E = T; cur = 1;
+      if (!E.ok) return MPC_STATUS_NUMERIC;
+      theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
+      phase = ls_start ? PH_LS : PH_DIR;
+      return MPC_RUNNING;
+    }
+    if (phase == PH_LS) {
+      lsm = false;
+      phase = PH_DIR;
+      /* estimates above constr_mult_init_max = 1000 are discarded (the iterate stays as it is) */
+      if (lmax <= 1000.0) {
+        E = T; cur = 1 - cur;
+        if (!E.ok) return MPC_STATUS_NUMERIC;
+      }
+      return MPC_RUNNING;
+    }
+    /* acceptance test of the line search */
+    bool accepted = false, ftype = false;
+    if (tiny) { accepted = T.ok; ftype = true; }
+    else if (T.ok) {
+      const double phi_t = df * T.f - mu * T.L;
+      const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
+      if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
+        const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
+        const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
+        if (theta_k <= theta_min && sw) {
+          if (armijo) accepted = true;
+        } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
+                   phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
+          accepted = true;
+        }
+        ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
+      }
+    }
+    if (accepted) {
+      if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
+      cur = 1 - cur;
+      E = T;
+      ++iter;
+      phase = PH_DIR;
+      return MPC_RUNNING;
+    }
+    if (tiny) return MPC_STATUS_LINESEARCH;
+    alpha *= 0.5; alpha_l = alpha;
+    if (alpha < amin) return MPC_STATUS_LINESEARCH;
+    phase = PH_BACKTRACK;
+    return MPC_RUNNING;
   }
 
   /* MPC.cpp:306-324: out9 and the optional N-point trajectory */

@@ -42,43 +42,87 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
  */
 constexpr size_t kStagingLdsBytes = 2u * mpc::STG_SLOT_PAIRS * 64u * 16u;   /* 36 KB per wave */
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)   /* over the active lanes of the wave */
+#else
+#define MPC_WAVE_ANY(p) (p)
+#endif
+
+/* Persistent form: a wave does not own 64 fixed instances.  Every lane takes the next unsolved instance from a
+ * global counter, solves it, writes its results and takes another one, until the counter passes B; the solver is a
+ * per-lane state machine (Solver::step), so the lanes of a wave may be on different instances in different phases.
+ * With a grid of ceil(B/64) waves this is the plain one-instance-per-lane launch; with fewer waves (instances_per_lane
+ * > 1) lanes that finish early do not idle until the slowest instance of their wave is done.
+ * Exit: a lane stops asking once the counter has passed B; the wave leaves when no lane holds an instance and none can
+ * get one -- every pass either advances an instance (bounded by max_iter) or consumes the counter. */
 template <bool STAGING>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const double *__restrict__ state,
     const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
     const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
-    const int64_t tile_doubles) {
+    const int64_t tile_doubles, int32_t *__restrict__ counter) {
   extern __shared__ double smem[];
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B) return;
-  double st[6], cf[MPC_NCOEF], w[MPC_NW];
-#pragma unroll
-  for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
-#pragma unroll
-  for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
-  if (weights) {
-#pragma unroll
-    for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
-  } else {
-#pragma unroll
-    for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
-  }
   using WS = mpc::TiledWorkspace<STAGING>;
   WS ws;
   ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
   ws.lane = threadIdx.x;
   ws.lbuf = (mpc::ldouble *)smem;
   mpc::Solver<WS> S(P, ws);
-  int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
-  if (s == MPC_STATUS_SUCCESS) s = S.solve();
-  double *o = out + i;
-  double *t = traj ? traj + i : nullptr;
-  const int64_t l = ldo;
-  S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; },
-           traj != nullptr);
-  status[i] = s;
-  if (iters) iters[i] = S.iters;
+  int64_t i = 0;
+  bool have = false, more = true;      /* holds an instance / may still get one */
+  int attempt = 0, it_total = 0;
+  for (;;) {
+    if (!have && more) {
+      i = (int64_t)atomicAdd(counter, 1);
+      more = i < B;
+      if (more) {
+        double st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+        for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+#pragma unroll
+        for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+        if (weights) {
+#pragma unroll
+          for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
+        } else {
+#pragma unroll
+          for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
+        }
+        const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
+        if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; have = true; }
+        else {
+          /* rejected at set-up (initial state outside its own bounds): report the start point, ask again */
+          double *o = out + i;
+          double *t = traj ? traj + i : nullptr;
+          const int64_t l = ldo;
+          S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; }, traj != nullptr);
+          status[i] = s0;
+          if (iters) iters[i] = 0;
+        }
+      }
+    }
+    if (!MPC_WAVE_ANY(have || more)) break;
+    if (have) {
+      const int r = S.step();
+      if (r != mpc::Solver<WS>::MPC_RUNNING) {
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+          /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
+          attempt = 1; it_total += S.iters;
+          S.start_point();
+          S.begin(false);
+        } else {
+          double *o = out + i;
+          double *t = traj ? traj + i : nullptr;
+          const int64_t l = ldo;
+          S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; }, traj != nullptr);
+          status[i] = r;
+          if (iters) iters[i] = S.iters + it_total;
+          have = false;
+        }
+      }
+    }
+  }
 }
 
 /* MPC::run pre-processing, one instance per lane (mpc_run_core.h).  rows of `pre`: state 0..5, coeffs 6..10,
@@ -172,7 +216,8 @@ struct MpcHandle {
   double *d_run = nullptr;    /* run(): pre[15] rows */
   double *d_run9 = nullptr;   /* run(): solve()'s 9 rows, caller's leading dimension */
   int64_t run9_ld = 0;
-  int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr;
+  int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
+  int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
   /* last call */
   int64_t last_B = 0;
   const int32_t *last_status = nullptr, *last_iters = nullptr;
@@ -228,6 +273,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_counter, sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
   *out = h;
   return MPC_OK;
 }
@@ -253,6 +300,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_iters) (void)hipFree(h->d_iters);
   if (h->d_rstat) (void)hipFree(h->d_rstat);
+  if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -270,14 +318,19 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
-  const unsigned grid = (unsigned)((B + kBlock - 1) / kBlock);
+  /* waves: one lane per instance, or fewer waves whose lanes take several instances in turn (instances_per_lane) */
+  const int64_t waves_full = (B + kBlock - 1) / kBlock;
+  int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
+  if (waves < 1) waves = 1;
+  const unsigned grid = (unsigned)waves;
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
   if (h->staging)
     hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, ldo, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride, h->d_counter);
   else
     hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride);
+                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride, h->d_counter);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
