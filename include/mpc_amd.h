@@ -118,7 +118,10 @@ int mpc_params_default(MpcParams *p);
 int mpc_params_load_json(const char *path, MpcParams *p);
 
 /* ---- lifetime -------------------------------------------------------------- */
-/* device < 0: current HIP device.  max_batch sizes the device workspace. */
+/* device < 0: current HIP device.  max_batch sizes the device workspace (4.75 KB per instance at N=10).
+ * A handle owns its workspace and launch state: calls on one handle must be ordered (one stream at a time).
+ * To keep several batches in flight -- which is how to fill the device, see DESIGN.md section 6b -- create one
+ * handle per stream. */
 int mpc_create(const MpcParams *p, int device, int64_t max_batch, MpcHandle **out);
 int mpc_set_params(MpcHandle *h, const MpcParams *p);
 void mpc_destroy(MpcHandle *h);
