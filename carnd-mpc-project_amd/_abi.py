@@ -36,7 +36,7 @@ class MpcParams(C.Structure):
         ("max_fit_order", C.c_int32), ("latency_ms", C.c_int32), ("max_fit_error", C.c_double),
         ("lookahead", C.c_double), ("steer_adj_thresh", C.c_double), ("steer_adj_ratio", C.c_double),
         ("ipopt_timeout", C.c_double), ("branch_mode", C.c_int32), ("precision", C.c_int32),
-        ("max_iter", C.c_int32), ("reserved0", C.c_int32), ("tol", C.c_double),
+        ("max_iter", C.c_int32), ("pass_cut", C.c_int32), ("tol", C.c_double),
     ]
 
     def copy(self):

@@ -1057,7 +1057,8 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   /* set-up: instance constants, start point (MPC.cpp:204-257)           */
   /* ------------------------------------------------------------------ */
-  MPC_HD int setup(const double *state6, const double *coef5, double yaw_lo, double yaw_hi, const double *w12) {
+  MPC_HD int setup(const double *state6, const double *coef5, double yaw_lo, double yaw_hi, const double *w12,
+                   bool write_start = true) {
     MPC_UNROLL
     for (int i = 0; i < 6; i++) st[i] = state6[i];
     MPC_UNROLL
@@ -1098,7 +1099,7 @@ struct Solver {
       psi0 = fmin(fmax(psi0, yl + pl), yu - pu);
     }
     psi_start = psi0;
-    start_point();
+    if (write_start) start_point();   /* a parked instance that is being resumed brings its iterate along */
     /* the fixed initial state must satisfy its own bounds (MPC.cpp:229-239 vs :269-281) */
     if (!(st[2] >= yl && st[2] <= yu) || !(fabs(st[3]) <= P.max_speed) || !(yl < yu)) return MPC_STATUS_INFEASIBLE;
     return MPC_STATUS_SUCCESS;
@@ -1133,6 +1134,27 @@ struct Solver {
       iters += it_total;
       return r;
     }
+  }
+
+  /* The state of an unfinished instance between two passes with phase == PH_DIR (everything else lives in the
+   * current iterate slot of the workspace or is recomputed by setup()): 36 values through an accessor a(q). */
+  enum { PARK_N = 36 };
+  template <class A> MPC_HD void park(A a, int attempt, int it_total) const {
+    a(0) = mu; a(1) = tau; a(2) = E.theta; a(3) = E.cinf; a(4) = E.f; a(5) = E.L; a(6) = E.dinf; a(7) = E.cmin; a(8) = E.cmax;
+    a(9) = E.lsum; a(10) = E.zsum; a(11) = fth0; a(12) = fth1; a(13) = fth2; a(14) = fth3; a(15) = fph0; a(16) = fph1;
+    a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
+    a(22) = (double)nf; a(23) = (double)iter; a(24) = (double)n_reg; a(25) = (double)cur; a(26) = E.ok ? 1.0 : 0.0;
+    a(27) = ls_start ? 1.0 : 0.0; a(28) = (double)attempt; a(29) = (double)it_total;
+    a(30) = 0.0; a(31) = 0.0; a(32) = 0.0; a(33) = 0.0; a(34) = 0.0; a(35) = 0.0;
+  }
+  template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
+    begin(a(27) != 0.0);
+    mu = a(0); tau = a(1); E.theta = a(2); E.cinf = a(3); E.f = a(4); E.L = a(5); E.dinf = a(6); E.cmin = a(7); E.cmax = a(8);
+    E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
+    fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
+    nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != 0.0;
+    attempt = (int)a(28); it_total = (int)a(29);
+    iters = iter; phase = PH_DIR;
   }
 
   MPC_HD void begin(bool ls) {

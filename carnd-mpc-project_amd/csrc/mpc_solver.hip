@@ -49,34 +49,56 @@ constexpr size_t kStagingLdsBytes = 2u * mpc::STG_SLOT_PAIRS * 64u * 16u;   /* 3
 #endif
 
 /* Persistent form: a wave does not own 64 fixed instances.  Every lane takes the next unsolved instance from a
- * global counter, solves it, writes its results and takes another one, until the counter passes B; the solver is a
- * per-lane state machine (Solver::step), so the lanes of a wave may be on different instances in different phases.
- * With a grid of ceil(B/64) waves this is the plain one-instance-per-lane launch; with fewer waves (instances_per_lane
- * > 1) lanes that finish early do not idle until the slowest instance of their wave is done.
- * Exit: a lane stops asking once the counter has passed B; the wave leaves when no lane holds an instance and none can
- * get one -- every pass either advances an instance (bounded by max_iter) or consumes the counter. */
+ * global counter, solves it, writes its results and takes another one, until the counter passes the end; the solver
+ * is a per-lane state machine (Solver::step), so the lanes of a wave may be on different instances in different
+ * phases.  With a grid of ceil(B/64) waves this is the plain one-instance-per-lane launch.
+ *
+ * Two-phase solve (MpcTwoPhase): a wave lasts as long as its slowest instance, and two thirds of the instances are
+ * done after ~10 iterations while the slowest need 25.  Phase A therefore PARKS an instance that is still running
+ * after `pass_cut` passes (at a pass boundary in the DIR phase: 36 scalars + its current iterate, which stays where
+ * it is) and appends it to a list; phase B, launched right behind on the same stream, is the same kernel taking its
+ * work from that list: a lane copies the parked iterate into its own tile, restores the scalars and carries on.  The
+ * arithmetic of an instance does not change (results are bitwise identical), but the unfinished third is re-packed
+ * into dense waves: ~19 % fewer wave passes, and as much less workspace traffic.
+ *
+ * Exit: a lane stops asking once its counter has passed the end; the wave leaves when no lane holds an instance and
+ * none can get one -- every pass either advances an instance (bounded by max_iter) or consumes the counter. */
+struct MpcTwoPhase {
+  int32_t *ctl;            /* [0] fresh counter, [1] number of parked instances, [2] resume counter */
+  int32_t *list_inst;      /* parked: instance index */
+  int32_t *list_src;       /* parked: wave * 64 + lane of the tile column that holds its iterate */
+  double *park;            /* [PARK_N][ld_park] solver scalars, column = position in the list */
+  int64_t ld_park;
+  const double *src_ws;    /* phase B: workspace of phase A */
+  int32_t pass_cut;        /* phase A: park after this many passes (0 = never) */
+  int32_t resume;          /* 1 = phase B */
+};
+
 template <bool STAGING>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const double *__restrict__ state,
     const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
     const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
-    const int64_t tile_doubles, int32_t *__restrict__ counter) {
+    const int64_t tile_doubles, const MpcTwoPhase T) {
   extern __shared__ double smem[];
   using WS = mpc::TiledWorkspace<STAGING>;
+  using SV = mpc::Solver<WS>;
   WS ws;
   ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
   ws.lane = threadIdx.x;
   ws.lbuf = (mpc::ldouble *)smem;
-  mpc::Solver<WS> S(P, ws);
+  SV S(P, ws);
   int64_t i = 0;
   bool have = false, more = true;      /* holds an instance / may still get one */
-  int attempt = 0, it_total = 0;
+  int attempt = 0, it_total = 0, passes = 0;
+  const int64_t n_work = T.resume ? (int64_t)T.ctl[1] : B;
   for (;;) {
     if (!have && more) {
-      i = (int64_t)atomicAdd(counter, 1);
-      more = i < B;
+      const int64_t pos = (int64_t)atomicAdd(T.ctl + (T.resume ? 2 : 0), 1);
+      more = pos < n_work;
       if (more) {
+        i = T.resume ? (int64_t)T.list_inst[pos] : pos;
         double st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
         for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
@@ -89,8 +111,23 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 #pragma unroll
           for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
         }
-        const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w);
-        if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; have = true; }
+        const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
+        if (T.resume) {
+          /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
+          const double *pk = T.park + pos;
+          const int64_t lp = T.ld_park;
+          S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
+          const int src = T.list_src[pos];
+          WS wsrc = ws;
+          wsrc.tile = (mpc::gdouble *)(T.src_ws + (int64_t)(src >> 6) * tile_doubles);
+          wsrc.lane = src & 63;
+          const int I = S.cur ? mpc::IT1 : mpc::IT0;
+          for (int k = 0; k < P.N - 1; ++k) {
+#pragma unroll
+            for (int f = 0; f < mpc::IT_SZ; f += 2) ws.store2(k, I, f, wsrc.it(k, I, f), wsrc.it(k, I, f + 1));
+          }
+          passes = 0; have = true;
+        } else if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
         else {
           /* rejected at set-up (initial state outside its own bounds): report the start point, ask again */
           double *o = out + i;
@@ -105,7 +142,8 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     if (!MPC_WAVE_ANY(have || more)) break;
     if (have) {
       const int r = S.step();
-      if (r != mpc::Solver<WS>::MPC_RUNNING) {
+      ++passes;
+      if (r != SV::MPC_RUNNING) {
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
           attempt = 1; it_total += S.iters;
@@ -120,6 +158,15 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
           if (iters) iters[i] = S.iters + it_total;
           have = false;
         }
+      } else if (T.pass_cut > 0 && passes >= T.pass_cut && S.phase == SV::PH_DIR) {
+        /* still running: park it for phase B */
+        const int64_t pos = (int64_t)atomicAdd(T.ctl + 1, 1);
+        T.list_inst[pos] = (int32_t)i;
+        T.list_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+        double *pk = T.park + pos;
+        const int64_t lp = T.ld_park;
+        S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
+        have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
       }
     }
   }
@@ -218,6 +265,11 @@ struct MpcHandle {
   int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
+  /* two-phase solve: second workspace, parked-instance list and scalars (allocated on first use) */
+  int pass_cut = 0;           /* MpcParams.pass_cut, or MPC_PASS_CUT in the environment (0 = single launch) */
+  int64_t two_phase_min = 8192;
+  double *ws2 = nullptr, *d_park = nullptr;
+  int32_t *d_list = nullptr;
   /* last call */
   int64_t last_B = 0;
   const int32_t *last_status = nullptr, *last_iters = nullptr;
@@ -273,7 +325,9 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void **)&h->d_counter, sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_counter, 4 * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  h->pass_cut = p->pass_cut > 0 ? p->pass_cut : 0;
+  if (const char *e3 = getenv("MPC_PASS_CUT")) { h->pass_cut = atoi(e3); if (h->pass_cut < 0) h->pass_cut = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
   *out = h;
   return MPC_OK;
@@ -301,6 +355,9 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_iters) (void)hipFree(h->d_iters);
   if (h->d_rstat) (void)hipFree(h->d_rstat);
   if (h->d_counter) (void)hipFree(h->d_counter);
+  if (h->ws2) (void)hipFree(h->ws2);
+  if (h->d_park) (void)hipFree(h->d_park);
+  if (h->d_list) (void)hipFree(h->d_list);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -322,15 +379,36 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  const unsigned grid = (unsigned)waves;
-  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), s));
+  const bool two = h->pass_cut > 0 && h->inst_per_lane == 1 && B >= h->two_phase_min;
+  if (two && !h->ws2) {
+    const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
+    MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 36 * h->io_stride));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 2 * h->io_stride));
+  }
+  MpcTwoPhase T;
+  T.ctl = h->d_counter; T.list_inst = h->d_list; T.list_src = h->d_list ? h->d_list + h->io_stride : nullptr;
+  T.park = h->d_park; T.ld_park = h->io_stride; T.src_ws = h->ws; T.pass_cut = two ? h->pass_cut : 0; T.resume = 0;
+  int32_t *it_out = iters ? iters : h->d_iters;
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  if (h->staging)
-    hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, ldo, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride, h->d_counter);
-  else
-    hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
-                       yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, h->ws, h->ws_stride, h->d_counter);
+  auto launch = [&](unsigned grid, double *wsp, const MpcTwoPhase &tp) {
+    if (h->staging)
+      hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, ldo, state, coeffs,
+                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, wsp, h->ws_stride, tp);
+    else
+      hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
+                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, wsp, h->ws_stride, tp);
+  };
+  launch((unsigned)waves, h->ws, T);
+  if (two) {
+    /* phase B: the parked instances, re-packed; its grid covers half the batch, and lanes take further work from the
+     * list if more than that was parked */
+    MPC_HIP_CHECK(hipGetLastError());
+    MpcTwoPhase R = T;
+    R.resume = 1; R.pass_cut = 0;
+    launch((unsigned)((waves + 1) / 2), h->ws2, R);
+  }
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;

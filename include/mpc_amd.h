@@ -95,7 +95,8 @@ typedef struct MpcParams {
   int32_t branch_mode;       /* MPC_BRANCH_FROZEN: CppAD tape recorded once at the start point */
   int32_t precision;         /* MPC_PRECISION_F64 */
   int32_t max_iter;          /* IPOPT default 3000; default here 200 */
-  int32_t reserved0;
+  int32_t pass_cut;          /* two-phase solve: park instances still running after this many passes and finish them,
+                              * re-packed, in a second launch (0 = single launch, the default) */
   double tol;                /* IPOPT "tol", default 1e-8 */
 } MpcParams;
 

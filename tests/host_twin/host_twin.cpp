@@ -75,3 +75,56 @@ extern "C" void mpc_host_twin_tel_pose(const MpcParams *p, const double *tel6, d
 extern "C" void mpc_host_twin_tel_cmd(const MpcParams *p, const double *o8, double *cmd2) {
   mpc::command_from_run(*p, o8, &cmd2[0], &cmd2[1]);
 }
+
+/* The two-phase solve of the device kernel, replayed on the host: run the state machine, PARK the instance after
+ * `pass_cut` passes (at a pass boundary in the DIR phase), then RESUME it in a different solver object on a different
+ * workspace that only receives the current iterate slot -- exactly what phase B of mpc_solve_kernel does. */
+extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, const double *state,
+                                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                          const double *weights, double *out, int32_t *status, int32_t *iters,
+                                          int32_t *was_parked) {
+  if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
+  const int N = p->N, M = N - 1;
+  using SV = mpc::Solver<mpc::HostWorkspace>;
+  std::vector<double> wsA((size_t)M * mpc::STAGE_SZ_GLOBAL), wsB((size_t)M * mpc::STAGE_SZ_GLOBAL, -7.0);
+  for (int64_t i = 0; i < B; i++) {
+    double st[6], cf[MPC_NCOEF], w[MPC_NW], park[SV::PARK_N];
+    for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+    for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : p->weights[q];
+    SV A(*p, mpc::HostWorkspace{wsA.data()});
+    int s = A.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0, passes = 0;
+    SV *fin = &A;
+    SV Bs(*p, mpc::HostWorkspace{wsB.data()});
+    was_parked[i] = 0;
+    if (s == MPC_STATUS_SUCCESS) {
+      A.begin(true);
+      SV *cur = &A;
+      for (;;) {
+        const int r = cur->step();
+        ++passes;
+        if (r != SV::MPC_RUNNING) {
+          if (r == MPC_STATUS_LINESEARCH && attempt == 0) { attempt = 1; it_total += cur->iters; cur->start_point(); cur->begin(false); continue; }
+          s = r; cur->iters += it_total; fin = cur;
+          break;
+        }
+        if (cur == &A && pass_cut > 0 && passes >= pass_cut && A.phase == SV::PH_DIR) {
+          A.park([&park](int q) -> double & { return park[q]; }, attempt, it_total);
+          std::fill(wsB.begin(), wsB.end(), -7.0);                      /* nothing but the iterate slot comes along */
+          Bs.setup(st, cf, yaw_lo[i], yaw_hi[i], w, false);
+          Bs.unpark([&park](int q) -> double { return park[q]; }, attempt, it_total);
+          const int I = Bs.cur ? mpc::IT1 : mpc::IT0;
+          for (int k = 0; k < M; k++)
+            for (int f = 0; f < mpc::IT_SZ; f++) wsB[(size_t)k * mpc::STAGE_SZ_GLOBAL + I + f] = wsA[(size_t)k * mpc::STAGE_SZ_GLOBAL + I + f];
+          cur = &Bs; was_parked[i] = 1;
+        }
+      }
+    }
+    double o9[9];
+    double *o = o9;
+    fin->unpack([o](int q) -> double & { return o[q]; }, [o](int) -> double & { return o[0]; }, false);
+    for (int q = 0; q < 9; q++) out[q * ld + i] = o9[q];
+    status[i] = s; iters[i] = fin->iters;
+  }
+  return MPC_OK;
+}

@@ -271,3 +271,27 @@ def test_staged_and_plain_kernels_are_bitwise_identical(pkg, golden_dir, waypoin
             os.environ.pop("MPC_STAGING", None)
         else:
             os.environ["MPC_STAGING"] = old
+
+
+def test_two_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """Parking unfinished instances after MPC_PASS_CUT passes and finishing them, re-packed, in a second launch must
+    not change a single bit: the same arithmetic on the same state, only in another lane."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    old = os.environ.get("MPC_PASS_CUT")
+    try:
+        for N, dt, B in ((10, 0.1, 16384 + 11), (25, 0.05, 8192)):
+            q = params.copy(); q.N = N; q.dt = dt
+            b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=78)
+            res = {}
+            for cut in ("0", "12", "5"):
+                os.environ["MPC_PASS_CUT"] = cut
+                res[cut] = gpu_solve(pkg, q, b, torch_dev)
+            for cut in ("12", "5"):
+                for key in ("out", "traj", "status", "iters"):
+                    assert np.array_equal(res[cut][key], res["0"][key]), (N, cut, key)
+            assert (res["0"]["status"] == 0).mean() > 0.999 and res["0"]["iters"].max() > 14   # some instances did get parked
+    finally:
+        if old is None:
+            os.environ.pop("MPC_PASS_CUT", None)
+        else:
+            os.environ["MPC_PASS_CUT"] = old

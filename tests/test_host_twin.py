@@ -124,3 +124,23 @@ def test_twin_light_math(host_twin):
     assert np.max(np.abs(at - np.arctan(xa)) / np.maximum(np.abs(np.arctan(xa)), 1e-300)) < 6e-16
     nz = xa != 0
     assert np.max(np.abs(lg[nz] - np.log(np.abs(xa[nz]))) / np.maximum(np.abs(np.log(np.abs(xa[nz]))), 1e-3)) < 5e-16
+
+
+@pytest.mark.parametrize("cut", [3, 12])
+def test_park_and_resume_is_bitwise_identical(pkg, host_twin, golden_dir, waypoints, cut):
+    """The two-phase solve (csrc/mpc_solver.hip: park after `cut` passes, resume in another lane on another workspace
+    that only receives the current iterate slot) replayed with the host build: not a bit may change."""
+    import ctypes as C
+    from helpers import vp
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 768
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=91)
+    ref = twin_solve(host_twin, params, b, want_traj=False)
+    st = np.ascontiguousarray(b["state"]); cf = np.ascontiguousarray(b["coeffs"])
+    yl = np.ascontiguousarray(b["yaw_lo"]); yh = np.ascontiguousarray(b["yaw_hi"])
+    out = np.zeros((9, B)); status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32); parked = np.zeros(B, dtype=np.int32)
+    rc = host_twin.mpc_host_twin_solve_parked(C.byref(params), C.c_int64(B), C.c_int64(B), C.c_int(cut), vp(st), vp(cf), vp(yl), vp(yh),
+                                              None, vp(out), vp(status), vp(iters), vp(parked))
+    assert rc == 0
+    assert parked.sum() > (B // 4 if cut == 12 else B - 5)
+    assert np.array_equal(out, ref["out"]) and np.array_equal(status, ref["status"]) and np.array_equal(iters, ref["iters"])
