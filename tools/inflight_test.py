@@ -15,7 +15,7 @@ st, cf, yl, yh = t(b['state']), t(b['coeffs']), t(b['yaw_lo']), t(b['yaw_hi'])
 for nfl in (1, 2, 3, 1, 2):
     hs = [pkg.BatchedMPC(params, B, device=0) for _ in range(nfl)]
     outs = [h.alloc_outputs(B, dev, want_traj=True) for h in hs]
-    ss = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(nfl)]
+    ss = [torch.cuda.Stream(device=dev, priority=int(os.environ.get('PRIO', -1))) for _ in range(nfl)]
     for i in range(nfl):
         hs[i].solve_torch(st, cf, yl, yh, outputs=outs[i], stream=ss[i])
     torch.cuda.synchronize()
