@@ -1159,7 +1159,10 @@ struct Solver {
 
   MPC_HD void begin(bool ls) {
     cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
-    phase = PH_EVAL0; iter = 0; ls_start = ls; tiny = false;
+    /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
+     * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
+     * when that estimate is rejected or not wanted */
+    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false;
     alpha = alpha_l = alpha_z = dw_cur = 0.0;
     theta_max = theta_min = dw_last = 0.0;
     theta_k = phi_k = pth = pdp = amin = 0.0;
@@ -1208,7 +1211,7 @@ struct Solver {
       if (okb) forward();
       dw_cur = dw;
       if (phase == PH_LS) {
-        if (!okb) { lsm = false; phase = PH_DIR; return MPC_RUNNING; }
+        if (!okb) { lsm = false; ls_start = false; phase = PH_EVAL0; return MPC_RUNNING; }
         alpha = 0.0; alpha_l = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
       } else {
         if (dw > 0.0) { dw_last = dw; n_reg++; }
@@ -1234,13 +1237,14 @@ struct Solver {
       return MPC_RUNNING;
     }
     if (phase == PH_LS) {
-      lsm = false;
-      phase = PH_DIR;
-      /* estimates above constr_mult_init_max = 1000 are discarded (the iterate stays as it is) */
+      lsm = false; ls_start = false;
+      /* estimates above constr_mult_init_max = 1000 are discarded: the start point is then evaluated as it is */
       if (lmax <= 1000.0) {
         E = T; cur = 1 - cur;
         if (!E.ok) return MPC_STATUS_NUMERIC;
-      }
+        theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
+        phase = PH_DIR;
+      } else phase = PH_EVAL0;
       return MPC_RUNNING;
     }
     /* acceptance test of the line search */
