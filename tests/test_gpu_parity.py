@@ -139,6 +139,23 @@ def test_scipy_goldens(pkg, golden_dir, torch_dev):
         assert np.max(np.abs(r["out"][:6] - ref[:6])) < 2e-5
 
 
+def test_scipy_goldens_long_horizon_and_weights(pkg, golden_dir, torch_dev):
+    """configs[3] (N=25, dt=0.05) and configs[4] (per-instance weights) against the independent SLSQP cross-solve."""
+    gold = load_golden("scipy_cross_solve_ext.json")
+    for sel, over in ((lambda c: c["N"] == 25, dict(N=25, dt=0.05)), (lambda c: c["weights"] is not None, {})):
+        cases = [c for c in gold["cases"] if sel(c)]
+        params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"), **over)
+        b = {"state": np.array([c["state"] for c in cases]).T.copy(), "coeffs": np.array([c["coef"] for c in cases]).T.copy(),
+             "yaw_lo": np.array([c["yaw_lo"] for c in cases]), "yaw_hi": np.array([c["yaw_hi"] for c in cases])}
+        w = np.array([c["weights"] for c in cases]).T.copy() if cases[0]["weights"] is not None else None
+        r = gpu_solve(pkg, params, b, torch_dev, weights=w)
+        assert (r["status"] == 0).all()
+        ref = np.array([c["out9"] for c in cases]).T
+        assert np.max(np.abs(r["out"][6] - ref[6])) < 5e-6
+        assert np.max(np.abs(r["out"][7] - ref[7])) < 5e-6
+        assert np.max(np.abs(r["out"][:6] - ref[:6])) < 5e-5
+
+
 def test_full_size_properties(pkg, golden_dir, waypoints, torch_dev):
     """BASELINE.json configs[2] at FULL size (65 536 lake-track states, config-fast.json): size-independent
     properties + a random sample against the oracle."""

@@ -144,3 +144,20 @@ def test_park_and_resume_is_bitwise_identical(pkg, host_twin, golden_dir, waypoi
     assert rc == 0
     assert parked.sum() > (B // 4 if cut == 12 else B - 5)
     assert np.array_equal(out, ref["out"]) and np.array_equal(status, ref["status"]) and np.array_equal(iters, ref["iters"])
+
+
+def test_twin_against_scipy_goldens_long_horizon_and_weights(pkg, host_twin, golden_dir):
+    gold = load_golden("scipy_cross_solve_ext.json")
+    for sel, over in ((lambda c: c["N"] == 25, dict(N=25, dt=0.05)), (lambda c: c["weights"] is not None, {})):
+        cases = [c for c in gold["cases"] if sel(c)]
+        assert len(cases) >= 6
+        params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"), **over)
+        b = {"state": np.array([c["state"] for c in cases]).T.copy(), "coeffs": np.array([c["coef"] for c in cases]).T.copy(),
+             "yaw_lo": np.array([c["yaw_lo"] for c in cases]), "yaw_hi": np.array([c["yaw_hi"] for c in cases])}
+        w = np.array([c["weights"] for c in cases]).T.copy() if cases[0]["weights"] is not None else None
+        r = twin_solve(host_twin, params, b, weights=w)
+        assert (r["status"] == 0).all()
+        ref = np.array([c["out9"] for c in cases]).T
+        assert np.max(np.abs(r["out"][6] - ref[6])) < 5e-6
+        assert np.max(np.abs(r["out"][7] - ref[7])) < 5e-6
+        assert np.max(np.abs(r["out"][:6] - ref[:6])) < 5e-5
