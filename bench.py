@@ -41,8 +41,8 @@ KFLOP_PER_STAGE_ITER = 2.5                                     # SURVEY.md secti
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--config", default="config-fast.json")
     ap.add_argument("--no-traj", action="store_true")
