@@ -76,22 +76,21 @@ enum : int {
   F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
   IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
   F_D = 2 * IT_SZ, D_N = 8,                                        /* direction (ds, du) */
-  F_GK = F_D + D_N, GK_N = 12,                                     /* gains K (HBM placement) */
-  F_GF = F_GK + GK_N, GF_N = 2,                                    /* gains kff (HBM placement) */
-  STAGE_SZ_LDS = F_GK,                                             /* 58 fields/stage with gains in LDS */
-  STAGE_SZ_GLOBAL = F_GF + GF_N                                    /* 72 fields/stage with gains in HBM */
+  STAGE_SZ_GLOBAL = F_D + D_N,                                     /* 52 fields per stage */
+  /* The Riccati gains K (2x6) and kff (2) live only between the backward and the forward sweep of one pass, while
+   * the iterate slot that is not the current one holds nothing (the next trial point is written there afterwards):
+   * they are stored in the first 14 fields of that slot.  The workspace is a fifth smaller for it, and the
+   * workspace stream does live in the caches (bypassing them costs 40 %). */
+  F_GK = 0, GK_N = 12, F_GF = F_GK + GK_N, GF_N = 2
 };
+static_assert(GK_N + GF_N <= IT_SZ, "the gains must fit an iterate slot");
 enum : int { D_S = 0, D_U = 6 };                                   /* direction entries */
 
-MPC_HD int64_t workspace_fields_per_instance(int N, bool gains_in_lds) {
-  return (int64_t)(N - 1) * (gains_in_lds ? STAGE_SZ_LDS : STAGE_SZ_GLOBAL);
-}
-/* LDS bytes per wavefront for the gains of an N-step horizon */
-MPC_HD int64_t gains_lds_bytes_per_wave(int N) { return (int64_t)(N - 1) * (GK_N + GF_N) * 8 * 64; }
+MPC_HD int64_t workspace_fields_per_instance(int N, bool) { return (int64_t)(N - 1) * STAGE_SZ_GLOBAL; }
 
 /* Staging interface (see TiledWorkspace): a sweep asks for the record of the NEXT stage while it works on the
  * current one.  stage_fetch_it copies the IT_SZ fields of an iterate slot of stage k to the front of buffer `buf`,
- * stage_fetch_x / stage_fetch_d the gains or the direction behind it; sit()/sx() read them back; stage_wait<N>()
+ * stage_fetch_g / stage_fetch_d the gains or the direction behind it; sit()/sg()/sx() read them back; stage_wait<N>()
  * waits until at most the N most recent copy/store instructions are still in flight.  On the host build all of
  * this degenerates to direct reads. */
 enum : int { STG_IT_OPS = IT_SZ / 2, STG_ITF_OPS = 8, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
@@ -109,12 +108,13 @@ struct HostWorkspace {
   MPC_HD void store2(int k, int I, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + I + f] = a; base[k * STAGE_SZ_GLOBAL + I + f + 1] = b; }
   MPC_HD void stage_fetch_it(int, int, int) const {}
   MPC_HD void stage_fetch_itf(int, int, int) const {}
-  MPC_HD void stage_fetch_x(int, int, int) const {}
   MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
   MPC_HD void stage_drain() const {}
   MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
   MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
+  MPC_HD void stage_fetch_g(int, int, int) const {}
+  MPC_HD double sg(int, int k, int J, int j) const { return base[k * STAGE_SZ_GLOBAL + J + j]; }
 };
 
 #if defined(__HIPCC__)
@@ -219,8 +219,9 @@ struct TiledWorkspace {
   MPC_HD void stage_fetch_itf(int buf, int k, int I) const {
     if (STAGING) { dma<4>(buf, k, I, F_S, F_S / 2); dma<4>(buf, k, I, F_ZL, F_ZL / 2); }
   }
-  MPC_HD void stage_fetch_x(int buf, int k, int F) const { if (STAGING) dma<STG_X_OPS>(buf, k, 0, F, STG_IT_OPS); }
   MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
+  /* the gains, in the first fields of iterate slot J (the one that is not current) */
+  MPC_HD void stage_fetch_g(int buf, int k, int J) const { if (STAGING) dma<STG_X_OPS>(buf, k, J, F_GK, STG_IT_OPS); }
   /* Between sweeps: a sweep's first copies read what the sweep before it stored, so all earlier stores of the
    * wave are waited for first.  (Vector memory operations of one wave are performed in order, and with
    * -DMPC_NO_DRAIN the results stay bitwise identical; the wait costs nothing measurable -- same-box A/B 2.02 vs
@@ -240,6 +241,7 @@ struct TiledWorkspace {
   }
   MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)it(k, I, j); }
   MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, 0, F + j); }
+  MPC_HD double sg(int buf, int k, int J, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, J, F_GK + j); }
 };
 #endif
 
@@ -527,7 +529,7 @@ struct Solver {
   /* inertia): the caller raises the regularisation dw and repeats.      */
   /* ------------------------------------------------------------------ */
   MPC_HD bool backward(double dw) {
-    const int I = it(cur);
+    const int I = it(cur), J = it(1 - cur);         /* J: where the gains go */
     /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1; only the lower triangle of the symmetric
      * matrices is ever written or read (PM/MX pick it), so the other half never occupies registers */
     double Pm[6][6], p[6], Pcc, pc;
@@ -638,7 +640,7 @@ struct Solver {
         const double det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > 0.0) || !(det > 0.0)) return false;
         const double idet = frcp1(det);
-        ws.store2(0, 0, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
+        ws.store2(0, J, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -705,8 +707,8 @@ struct Solver {
       }
       const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
       MPC_UNROLL
-      for (int j = 0; j < 6; j += 2) { ws.store2(k, 0, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, 0, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
-      ws.store2(k, 0, F_GF, kfd, kfa);
+      for (int j = 0; j < 6; j += 2) { ws.store2(k, J, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, J, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
+      ws.store2(k, J, F_GF, kfd, kfa);
       /* ---- value function of stage k ---- */
       double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
@@ -744,7 +746,7 @@ struct Solver {
   /* forward sweep: Newton direction ds, du; step limits; dphi           */
   /* ------------------------------------------------------------------ */
   MPC_HD void forward() {
-    const int I = it(cur);
+    const int I = it(cur), J = it(1 - cur);
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
     double ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
     double rmax = 0.0, rzmax = 0.0;                 /* largest step ratios: alpha = min(1, tau / ratio) */
@@ -755,13 +757,13 @@ struct Solver {
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
     ws.stage_fetch_itf(0, 0, I);
-    ws.stage_fetch_x(0, 0, F_GK);
+    ws.stage_fetch_g(0, 0, J);
     MPC_STAGE_LOOP
     for (int k = 0; k < M; ++k) {
       const int bf = k & 1;
       if (k + 1 < M) {
         ws.stage_fetch_itf(bf ^ 1, k + 1, I);
-        ws.stage_fetch_x(bf ^ 1, k + 1, F_GK);
+        ws.stage_fetch_g(bf ^ 1, k + 1, J);
         if (k == 0) ws.template stage_wait<STG_ITF_OPS + STG_X_OPS>();
         else ws.template stage_wait<STG_ITF_OPS + STG_X_OPS + ST_FORWARD>();
       } else ws.template stage_wait<0>();
@@ -772,12 +774,12 @@ struct Solver {
       const double delta = ws.sit(bf, k, I, F_U + 0), acc = ws.sit(bf, k, I, F_U + 1);
       Lin L;
       linearise(sk, delta, acc, sn, L);
-      double dd = ws.sx(bf, k, F_GK, GK_N + 0), da = ws.sx(bf, k, F_GK, GK_N + 1);
+      double dd = ws.sg(bf, k, J, GK_N + 0), da = ws.sg(bf, k, J, GK_N + 1);
       if (k > 0) {
-        dd += ws.sx(bf, k, F_GK, 0) * d0 + ws.sx(bf, k, F_GK, 1) * d1 + ws.sx(bf, k, F_GK, 2) * d2 + ws.sx(bf, k, F_GK, 3) * d3 +
-              ws.sx(bf, k, F_GK, 4) * d5 + ws.sx(bf, k, F_GK, 5) * ddprev;
-        da += ws.sx(bf, k, F_GK, 6) * d0 + ws.sx(bf, k, F_GK, 7) * d1 + ws.sx(bf, k, F_GK, 8) * d2 + ws.sx(bf, k, F_GK, 9) * d3 +
-              ws.sx(bf, k, F_GK, 10) * d5 + ws.sx(bf, k, F_GK, 11) * ddprev;
+        dd += ws.sg(bf, k, J, 0) * d0 + ws.sg(bf, k, J, 1) * d1 + ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3 +
+              ws.sg(bf, k, J, 4) * d5 + ws.sg(bf, k, J, 5) * ddprev;
+        da += ws.sg(bf, k, J, 6) * d0 + ws.sg(bf, k, J, 7) * d1 + ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3 +
+              ws.sg(bf, k, J, 10) * d5 + ws.sg(bf, k, J, 11) * ddprev;
       }
       const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const double n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];

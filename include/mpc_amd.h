@@ -119,7 +119,7 @@ int mpc_params_default(MpcParams *p);
 int mpc_params_load_json(const char *path, MpcParams *p);
 
 /* ---- lifetime -------------------------------------------------------------- */
-/* device < 0: current HIP device.  max_batch sizes the device workspace (4.75 KB per instance at N=10).
+/* device < 0: current HIP device.  max_batch sizes the device workspace (3.7 KB per instance at N=10).
  * A handle owns its workspace and launch state: calls on one handle must be ordered (one stream at a time).
  * To keep several batches in flight -- which is how to fill the device, see DESIGN.md section 6b -- create one
  * handle per stream. */
