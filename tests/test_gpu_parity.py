@@ -312,3 +312,23 @@ def test_two_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_
             os.environ.pop("MPC_PASS_CUT", None)
         else:
             os.environ["MPC_PASS_CUT"] = old
+
+
+@pytest.mark.parametrize("N,dt", [(3, 0.1), (4, 0.05), (40, 0.025), (64, 0.02)])
+def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N, dt):
+    """The shortest horizons the ABI accepts (N=3: two transitions) and the longest (MPC_MAX_N = 64), ragged batch."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"), N=N, dt=dt)
+    cfg = O.load_config("config-fast.json", N=N, dt=dt)
+    B = 200 + 37
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=60 + N)
+    r = gpu_solve(pkg, params, b, torch_dev)
+    ok = r["status"] == 0
+    assert ok.mean() > 0.97
+    idx = [int(i) for i in np.where(ok)[0][:: max(1, B // 24)]]
+    ref = oracle_solve_batch(cfg, b, idx)
+    good = ref["status"] == 0
+    assert good.sum() >= len(idx) - 2
+    sel = np.array(idx)[good]
+    assert np.max(np.abs(r["out"][6, sel] - ref["out"][6, good])) < (1e-6 if N <= 10 else 5e-6)
+    assert np.max(np.abs(r["out"][:6, sel] - ref["out"][:6, good])) < 5e-5
+    assert np.max(np.abs(r["traj"][:, sel] - ref["traj"][:, good])) < 1e-4
