@@ -12,7 +12,7 @@ NCOEF = 5
 NSTATE = 6
 NOUT = 9
 MAX_N = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric"}
 ERR_NAMES = {0: "MPC_OK", -1: "MPC_ERR_INVALID", -2: "MPC_ERR_NO_DEVICE", -3: "MPC_ERR_HIP",
@@ -37,6 +37,8 @@ class MpcParams(C.Structure):
         ("lookahead", C.c_double), ("steer_adj_thresh", C.c_double), ("steer_adj_ratio", C.c_double),
         ("ipopt_timeout", C.c_double), ("branch_mode", C.c_int32), ("precision", C.c_int32),
         ("max_iter", C.c_int32), ("pass_cut", C.c_int32), ("tol", C.c_double),
+        ("out_step_tol", C.c_double), ("tol_f32", C.c_double), ("polish", C.c_int32),
+        ("reserved_i", C.c_int32 * 3), ("reserved_d", C.c_double * 2),
     ]
 
     def copy(self):

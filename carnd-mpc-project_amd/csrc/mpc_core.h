@@ -428,6 +428,7 @@ struct Eval {
   double dinf;   /* ||grad_x Lagrangian||_inf (scaled objective) */
   double cmin, cmax; /* range of slack*dual products */
   double lsum, zsum; /* ||lam||_1, ||z||_1 */
+  double du0;        /* max(|d delta_0|, |d a_0|) of the direction this trial was made with (unscaled by alpha) */
   bool ok;
 };
 
@@ -841,7 +842,7 @@ struct Solver {
     const int I = it(cur), J = it(1 - cur);
     const double hxy = (lsm ? 1.0 : 0.0) + dw;
     Eval R;
-    R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.ok = true;
+    R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.du0 = 0; R.ok = true;
     lmax = 0.0;
     const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
     /* carried from step k+1 -- current iterate: s_{k+1}, u_k, lam_{k+1}, d(delta_k), lam+_{k+1} */
@@ -878,6 +879,7 @@ struct Solver {
         n_del_o = ws.sit(bk, r, I, F_U + 0); n_acc_o = ws.sit(bk, r, I, F_U + 1);
         const double ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
         n_ddk = ddel;
+        if (r == 0) R.du0 = fmax(fabs(ddel), fabs(dacc));   /* the outputs' part of the step (termination polish) */
         /* ---- costate: lam+_k ---- */
         double dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
         if (with_costate) {
@@ -1112,9 +1114,11 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   enum { MPC_RUNNING = -1 };
   enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
+  enum { kMaxPolish = 6 };
   /* state of the interior-point loop (see step()) */
-  int phase, iter;
+  int phase, iter, n_polish;
   bool ls_start, tiny;
+  double out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   double alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
   double theta_k, phi_k, pth, pdp, amin;   /* line-search state */
 
@@ -1147,7 +1151,7 @@ struct Solver {
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
     a(22) = (double)nf; a(23) = (double)iter; a(24) = (double)n_reg; a(25) = (double)cur; a(26) = E.ok ? 1.0 : 0.0;
     a(27) = ls_start ? 1.0 : 0.0; a(28) = (double)attempt; a(29) = (double)it_total;
-    a(30) = 0.0; a(31) = 0.0; a(32) = 0.0; a(33) = 0.0; a(34) = 0.0; a(35) = 0.0;
+    a(30) = out_step; a(31) = (double)n_polish; a(32) = 0.0; a(33) = 0.0; a(34) = 0.0; a(35) = 0.0;
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
     begin(a(27) != 0.0);
@@ -1155,7 +1159,7 @@ struct Solver {
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
     nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != 0.0;
-    attempt = (int)a(28); it_total = (int)a(29);
+    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31);
     iters = iter; phase = PH_DIR;
   }
 
@@ -1164,7 +1168,7 @@ struct Solver {
     /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
-    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false;
+    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = 1e300;
     alpha = alpha_l = alpha_z = dw_cur = 0.0;
     theta_max = theta_min = dw_last = 0.0;
     theta_k = phi_k = pth = pdp = amin = 0.0;
@@ -1186,11 +1190,23 @@ struct Solver {
         iters = iter;
         const double E0 = kkt_error(E, 0.0);
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
-        if (E0 <= P.tol) return MPC_STATUS_SUCCESS;
+        if (E0 <= P.tol) {
+          /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
+           * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
+           * that the point returned is the central-path point itself and not whichever iterate crossed tol first
+           * (an interior a_0 still moves by ~1e-4 per step there).  At most kMaxPolish extra iterations. */
+          if (!P.polish || n_polish >= kMaxPolish || iter >= P.max_iter || (mu <= mu_floor && out_step <= P.out_step_tol))
+            return MPC_STATUS_SUCCESS;
+          ++n_polish;
+          if (mu > mu_floor) { mu = mu_floor; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; }
+        }
         if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
         /* barrier update, W&B eq. (7) */
         while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
           mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
+          /* with the termination polish the solve ends at the floor anyway: a value within 3x of it (IPOPT's schedule
+           * lands on 2.4e-9 before 1e-9) goes there directly, which saves most instances one iteration */
+          if (P.polish && mu < 3.0 * mu_floor) mu = mu_floor;
           tau = fmax(IpmConst::tau_min, 1.0 - mu);
           nf = 0;
         }
@@ -1271,6 +1287,7 @@ struct Solver {
       if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
       cur = 1 - cur;
       E = T;
+      out_step = alpha * T.du0;
       ++iter;
       phase = PH_DIR;
       return MPC_RUNNING;

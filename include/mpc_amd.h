@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 1
+#define MPC_ABI_VERSION 2
 #define MPC_MAX_TABLE 16
 #define MPC_NW 12      /* Config::weights entries read by FG_eval (Config.h:14-61) */
 #define MPC_NCOEF 5    /* road polynomial, zero padded: fit order is 2..4 (RoadGeometry.cpp:26-34) */
@@ -98,6 +98,19 @@ typedef struct MpcParams {
   int32_t pass_cut;          /* two-phase solve: park instances still running after this many passes and finish them,
                               * re-packed, in a second launch (0 = single launch, the default) */
   double tol;                /* IPOPT "tol", default 1e-8 */
+  /* Termination polish (default on).  IPOPT stops at the FIRST iterate whose scaled optimality error is <= tol
+   * (MPC.cpp:290-292 leaves that default untouched).  An output that the objective determines only weakly -- an
+   * interior a0: the frozen tape has no a^2 term -- then still moves by up to ~1e-4 per Newton step, so two correct
+   * solvers that stop one iterate apart differ by that much.  With polish != 0 an instance is converged when
+   * E_0 <= tol AND the barrier parameter has reached its floor (tol/10) AND the last accepted step moved
+   * (delta0, a0) by at most out_step_tol: the returned point is then the central-path point IPOPT is converging
+   * to, reproducible to ~1e-7 whatever the linear algebra (and a barrier parameter within 3x of the floor goes
+   * to the floor directly).  Cost: +0.4 iterations per solve.  polish = 0 is IPOPT's own stopping rule. */
+  double out_step_tol;       /* default 3e-7 (rad, m/s^2): leaves delta0 within 7e-8 and a0 within 2e-8 of the limit point */
+  double tol_f32;            /* "tol" of the MPC_PRECISION_F32 solver, default 1e-4 (see DESIGN.md, fp32 mode) */
+  int32_t polish;            /* default 1 */
+  int32_t reserved_i[3];
+  double reserved_d[2];
 } MpcParams;
 
 typedef struct MpcHandle MpcHandle;

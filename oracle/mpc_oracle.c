@@ -696,6 +696,7 @@ typedef struct Nlp {
 void orc_default_options(OrcSolveOptions *o) {
   o->branch_mode = ORC_BRANCH_FROZEN; o->max_iter = 500; o->tol = 1e-8;
   o->lam_init_ls = 1; o->obj_scaling = 1; o->verbose = 0;
+  o->polish = 1; o->out_step_tol = 3e-7;
 }
 
 typedef struct Filter { double th[256], ph[256]; int n; } Filter;
@@ -780,7 +781,8 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   double theta0 = 0; for (int j = 0; j < m; j++) theta0 += fabs(c[j]);
   const double theta_max = 1e4 * fmax(1, theta0), theta_min = 1e-4 * fmax(1, theta0);
   flt->n = 0;
-  int iter;
+  int iter, n_polish = 0;
+  double out_step = DBL_MAX;   /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   for (iter = 0; iter <= opt->max_iter; iter++) {
     double f = eval_f(P->cfg, &P->tape, x);
     eval_grad_f(P->cfg, &P->tape, x, g);
@@ -807,13 +809,22 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     info->dual_inf = dinf / df; info->compl_inf = COMPL(0.0) / df; info->iterations = iter;
     if (opt->verbose) fprintf(stderr, "it %3d f=%.10g theta=%.3e dinf=%.3e compl=%.3e mu=%.2e E0=%.3e\n", iter, f, cinf, dinf, COMPL(0.0), mu, E0);
     if (!(E0 == E0)) { status = ORC_NUMERIC_ERROR; break; }
-    if (E0 <= opt->tol) { status = ORC_SUCCESS; break; }
+    if (E0 <= opt->tol) {
+      /* IPOPT stops at the first iterate with E_0 <= tol.  Termination polish (OrcSolveOptions.polish, see
+       * mpc_oracle.h): Newton steps at the final barrier parameter until the outputs have stopped moving. */
+      if (!opt->polish || n_polish >= 6 || iter == opt->max_iter || (mu <= mu_min_abs && out_step <= opt->out_step_tol)) {
+        status = ORC_SUCCESS; break;
+      }
+      n_polish++;
+      if (mu > mu_min_abs) { mu = mu_min_abs; tau = fmax(tau_min, 1 - mu); flt->n = 0; }
+    }
     if (iter == opt->max_iter) break;
     /* barrier update (W&B eq. 7), repeated while the barrier problem is already solved */
     for (;;) {
       double Emu = fmax(fmax(dinf / sd, cinf), COMPL(mu) / sc);
       if (Emu <= kappa_eps * mu && mu > mu_min_abs) {
         mu = fmax(mu_min_abs, fmin(kappa_mu * mu, pow(mu, theta_mu)));
+        if (opt->polish && mu < 3.0 * mu_min_abs) mu = mu_min_abs;   /* polish ends at the floor anyway (see mpc_oracle.h) */
         tau = fmax(tau_min, 1 - mu); flt->n = 0;
       } else break;
     }
@@ -902,6 +913,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     if (!accepted) { status = ORC_RESTORATION_FAILURE; break; }
     if (!ftype && flt->n < 256) { flt->th[flt->n] = (1 - gamma_theta) * theta_k; flt->ph[flt->n] = phi_k - gamma_phi * theta_k; flt->n++; }
     memcpy(x, xt, szn);
+    out_step = alpha * fmax(fabs(dx[P->I.delta]), fabs(dx[P->I.a]));
     for (int j = 0; j < m; j++) lam[j] += alpha * dlam[j];
     for (int i = 0; i < n; i++) {
       if (hl[i]) {

@@ -72,10 +72,5 @@ def assert_parity(got_out, ref_out, got_traj=None, ref_traj=None, what="", tol_a
     return d_steer, d_acc, d_state
 
 
-def sol_from_outputs(N, state, traj, out, full=None):
-    """Not every output carries the full decision vector; helper kept for KKT checks on oracle solutions."""
-    return full
-
-
 def load_golden(name):
     return json.load(open(os.path.join(ROOT, "tests", "golden", name)))

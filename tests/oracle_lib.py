@@ -35,7 +35,8 @@ class OrcConfig(C.Structure):
 
 class OrcSolveOptions(C.Structure):
     _fields_ = [("branch_mode", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
-                ("lam_init_ls", C.c_int), ("obj_scaling", C.c_int), ("verbose", C.c_int)]
+                ("lam_init_ls", C.c_int), ("obj_scaling", C.c_int), ("verbose", C.c_int),
+                ("polish", C.c_int), ("out_step_tol", C.c_double)]
 
 
 class OrcSolveInfo(C.Structure):

@@ -94,16 +94,10 @@ def test_long_horizon_matches_oracle(pkg, golden_dir, waypoints, torch_dev):
     idx = range(0, B, 4)
     cfg = O.load_config("config-stable.json", N=25, dt=0.05)
     ref = oracle_solve_batch(cfg, b, idx)
-    # At IPOPT's default tol = 1e-8 an INTERIOR a0 is only weakly determined (the frozen objective has no
-    # a^2 term, its curvature comes through v alone): two correct solvers stop up to ~1e-4 apart in a0 while
-    # agreeing in cost to 1e-9 and in delta0 to 1e-8.  So at the default tolerance a0 gets 1e-4 here ...
-    assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25", tol_accel=1e-4)
-    # ... and with both solvers tightened to 1e-10 they meet in the same point to the stated 1e-6.
-    tight = params.copy(); tight.tol = 1e-10
-    rt = gpu_solve(pkg, tight, b, torch_dev)
-    reft = oracle_solve_batch(cfg, b, idx, opt=O.default_options(tol=1e-10))
-    assert (rt["status"] == 0).all() and (reft["status"] == 0).all()
-    assert_parity(rt["out"][:, ::4], reft["out"], rt["traj"][:, ::4], reft["traj"], "N=25 tol 1e-10")
+    # default parameters: tol = 1e-8 with the termination polish (MpcParams.polish) in both solvers, so the
+    # stated 1e-6 holds for a0 too -- interior a0 included, which IPOPT's own stopping rule leaves ~1e-4 loose
+    assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25")
+    assert (ref["status"] == 0).all()
 
 
 def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev):
@@ -116,9 +110,8 @@ def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev
     assert (r["status"] == 0).all()
     idx = list(range(0, B, 4))
     ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
-    ok = ref["status"] == 0
-    assert ok.sum() >= len(idx) - 2
-    assert_parity(r["out"][:, idx][:, ok], ref["out"][:, ok], r["traj"][:, idx][:, ok], ref["traj"][:, ok], "weights")
+    assert (ref["status"] == 0).all()
+    assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "weights")
     w2 = w.copy(); w2[6] = 777.0              # acceleration weight: no effect under the frozen tape (F3a)
     r2 = gpu_solve(pkg, params, b, torch_dev, weights=w2)
     assert np.array_equal(r2["out"], r["out"])
@@ -322,13 +315,8 @@ def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N,
     B = 200 + 37
     b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=60 + N)
     r = gpu_solve(pkg, params, b, torch_dev)
-    ok = r["status"] == 0
-    assert ok.mean() > 0.97
-    idx = [int(i) for i in np.where(ok)[0][:: max(1, B // 24)]]
+    assert (r["status"] == 0).all(), np.bincount(r["status"])           # every instance of these batches converges
+    idx = list(range(0, B, max(1, B // 24)))                            # the dense oracle takes ~2 s per solve at N = 64
     ref = oracle_solve_batch(cfg, b, idx)
-    good = ref["status"] == 0
-    assert good.sum() >= len(idx) - 2
-    sel = np.array(idx)[good]
-    assert np.max(np.abs(r["out"][6, sel] - ref["out"][6, good])) < (1e-6 if N <= 10 else 5e-6)
-    assert np.max(np.abs(r["out"][:6, sel] - ref["out"][:6, good])) < 5e-5
-    assert np.max(np.abs(r["traj"][:, sel] - ref["traj"][:, good])) < 1e-4
+    assert (ref["status"] == 0).all(), np.bincount(ref["status"])
+    assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "N=%d" % N)

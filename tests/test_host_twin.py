@@ -48,11 +48,27 @@ def test_twin_long_horizon(pkg, host_twin, golden_dir, waypoints):
     assert (r["status"] == 0).all()
     cfg = O.load_config("config-stable.json", N=25, dt=0.05)
     ref = oracle_solve_batch(cfg, b, range(24))
-    assert_parity(r["out"], ref["out"], r["traj"], ref["traj"], "N=25", tol_accel=1e-4)   # see test_gpu_parity
-    tight = params.copy(); tight.tol = 1e-10
-    rt = twin_solve(host_twin, tight, b)
-    reft = oracle_solve_batch(cfg, b, range(24), opt=O.default_options(tol=1e-10))
-    assert_parity(rt["out"], reft["out"], rt["traj"], reft["traj"], "N=25 tol 1e-10")
+    # default parameters (tol = 1e-8 with the termination polish): the stated 1e-6 on a0 holds, interior a0 included
+    assert_parity(r["out"], ref["out"], r["traj"], ref["traj"], "N=25")
+
+
+def test_termination_polish_pins_weakly_determined_outputs(pkg, host_twin, golden_dir, waypoints):
+    """IPOPT's stopping rule (polish = 0) leaves an interior a0 up to ~1e-4 from the limit point: shown here by
+    solving the same instances at two tolerances.  With the polish the answers agree to the stated 1e-6 whatever
+    iterate crossed the tolerance first, at a cost of less than one iteration per solve."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
+    b = pkg.scenarios.lake_track_batch(2048, params, waypoints, seed=42)
+    exact = params.copy(); exact.out_step_tol = 1e-14                  # polish to the limit point (6 extra steps at most)
+    re_ = twin_solve(host_twin, exact, b, want_traj=False)
+    plain = params.copy(); plain.polish = 0
+    rp = twin_solve(host_twin, plain, b, want_traj=False)
+    r = twin_solve(host_twin, params, b, want_traj=False)
+    ok = (re_["status"] == 0) & (rp["status"] == 0) & (r["status"] == 0)
+    assert ok.sum() >= 2045
+    assert np.max(np.abs(rp["out"][7] - re_["out"][7])[ok]) > 1e-5      # the slack the polish removes
+    assert np.max(np.abs(r["out"][7] - re_["out"][7])[ok]) < 1e-7
+    assert np.max(np.abs(r["out"][6] - re_["out"][6])[ok]) < 1e-7
+    assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.6
 
 
 def test_twin_per_instance_weights(pkg, host_twin, golden_dir, waypoints):

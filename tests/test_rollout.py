@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from helpers import TEST_CPP
+from helpers import TEST_CPP, TOL_ACCEL, TOL_STEER, TOL_TRAJ
 
 
 def _oracle_rollout(cfg, state, coef, ylo, yhi, steps):
@@ -95,9 +95,9 @@ def test_rollout_batch_matches_oracle(pkg, golden_dir, waypoints):
         if worst != 0:
             continue
         checked += 1
-        assert np.max(np.abs(hist[:, 6, i] - oh[:, 6])) < 5e-6
-        assert np.max(np.abs(hist[:, 7, i] - oh[:, 7])) < 1e-4
-        assert np.max(np.abs(hist[:, :6, i] - oh[:, :6])) < 1e-4
+        assert np.max(np.abs(hist[:, 6, i] - oh[:, 6])) < TOL_STEER      # every step of the closed loop, default parameters
+        assert np.max(np.abs(hist[:, 7, i] - oh[:, 7])) < TOL_ACCEL
+        assert np.max(np.abs(hist[:, :6, i] - oh[:, :6])) < TOL_TRAJ
     assert checked >= 24
 
 
