@@ -2,62 +2,161 @@
 """bench.py -- MPC solves/sec of the batched HIP path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+     or plain `python bench.py --gpus N`, which starts the N ranks itself -- see spawn_ranks)
 
 A "step" is one pass of the hot path (the batched replacement of MPC::solve(), src/control/MPC.cpp:183-325)
-over one batch of synthetic inputs that are ALREADY RESIDENT IN HBM.  Workload at every N: BASELINE.json
+over one batch of synthetic inputs that are ALREADY RESIDENT IN HBM.  Default workload at every N: BASELINE.json
 configs[2] per GPU -- 65 536 lake-track states with 100 ms latency compensation, N=10, dt=0.1,
 config-fast.json, fp64, trajectories requested -- i.e. weak scaling: each rank solves its own 65 536
 instances (different PRNG streams), and every batch's per-instance results are gathered with a single
 all_gather_into_tensor (RCCL) inside the timed region.  Rank 0 prints ONE JSON line.
+
+Other BASELINE.json configurations through flags (same kernels, parity-tested in tests/):
+    configs[3]  --N 25 --dt 0.05 --config config-stable.json --scaling strong --global-batch 262144
+    configs[4]  --weights-sweep --precision f32 --no-traj --scaling strong --global-batch 1048576
 
 Steps are pipelined the way a serving loop would run them: `--inflight` (default 2) handles on separate streams,
 so the next batch's waves take the SIMDs that the previous launch frees in its tail, and the gather of batch i
 overlaps the solve of batch i+1 (sharding.PackedGather).  All K steps, solves and gathers, complete inside the
 timed region (barrier + synchronize on both sides).
 
-roofline: bound "hbm" with ALGORITHMIC bytes = 336 B/solve (in 104 + out 72 +
-trajectory 160) x solves per launch / the solve kernel's average launch duration measured live with HIP
-events on the launch stream.  The path is fp64-VALU/latency bound, so the HBM fraction is tiny by
-construction; `fp64_valu_frac` next to it prices the timed region against the 78.6 TFLOP/s vector peak
-using the algorithmic flop count of section 8d (2.5 kflop x stages x iterations).
-cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port"), one thread, a bounded sample of the same batch.
+roofline: bound "hbm" with ALGORITHMIC bytes per solve (fp64 336 B = in 104 + out 72 +
+trajectory 160; fp32 weight sweep 136 B) x solves per launch / the solve kernel's average launch duration measured
+live with HIP events on the launch stream.  `traffic` is what the kernel really moves through the L2's memory side
+(rocprofv3 FETCH_SIZE/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes): it is read from the committed PMC
+summary of the same workload (profiles/), never measured in this run -- `traffic_source` says so.  The path is
+VALU/latency bound by its algorithmic bytes, so `frac` is tiny by construction; `valu_frac` prices the timed region
+against the vector peak of the dtype (78.6 TFLOP/s fp64, 157.3 fp32) with the flop count of section 8d.
+cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port") on a bounded sample of the same batch: one thread
+(the way the reference runs), and all host cores of this box's share (`cpu_baseline_all_cores`).
+host_path: the same batch through mpc_solve_batch_host (pageable host arrays -> one H2D, solve, one D2H), and the
+latency of a B = 1 solve, which is what the reference's MPC::solve() drop-in does per telemetry message.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_SOLVE = 8 * (6 + 5 + 2) + 8 * 9 + 8 * 2 * 10   # 104 in + 72 out + 160 trajectory = 336 (N=10)
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_VALU_PEAK_TFLOPS = 78.6                                   # SURVEY.md section 8d
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}                 # SURVEY.md section 8d / MI355X_MICROARCH.md
 KFLOP_PER_STAGE_ITER = 2.5                                     # SURVEY.md section 8d
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-batch", type=int, default=0, help="--scaling strong: total instances, split evenly over the GPUs")
     ap.add_argument("--config", default="config-fast.json")
     ap.add_argument("--no-traj", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--precision", choices=("f64", "f32"), default="f64", help="f32 = MPC_PRECISION_F32 (BASELINE.json configs[4])")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline legs (one thread + all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive and B=1 latency measurements")
     ap.add_argument("--N", type=int, default=0, help="override Config::N (BASELINE.json configs[3]: 25)")
     ap.add_argument("--dt", type=float, default=0.0, help="override Config::dt (configs[3]: 0.05)")
     ap.add_argument("--weights-sweep", action="store_true", help="per-instance Config::weights (configs[4])")
+    ap.add_argument("--unfiltered", action="store_true", help="draw the instances without the generator's rejection step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
-                    "rehearse the multi-process path on a single GPU)")
+                    "rehearse the multi-process path on a single GPU or with --stub)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (handles on separate streams)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
-    args = ap.parse_args()
+    ap.add_argument("--stub", default="", help="TEST ONLY (tests/test_bench_spawn.py): 'host_twin' replaces the device solve by "
+                    "the CPU build of the solver header so that the multi-process plumbing can be exercised without a GPU; "
+                    "the line it prints is marked as a stub and is not a measurement")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, the same
+    environment contract as torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and pass
+    rank 0's JSON line through.  This parent never touches the GPU: it imports neither torch nor the HIP library
+    (asserted below), so nothing is ever exec'd or forked from a process that has initialised the device."""
+    import socket
+    assert "torch" not in sys.modules and "carnd_mpc_project_amd" not in sys.modules, "the spawning parent must stay GPU-free"
+    with open("/proc/self/maps") as f:
+        assert "libamdhip64" not in f.read(), "the spawning parent must stay GPU-free"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    print("bench parent: spawned %d ranks itself (no launcher); parent made no GPU call" % args.gpus, file=sys.stderr)
+    return rc
+
+
+def cpu_baseline_legs(args, batch, w_np, over, status, out_np, budget):
+    """The checker, timed as the CPU baseline (kind "port"): one thread first, then every core of this box's share."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multiprocessing as mp
+    import numpy as np
+    import oracle_lib as O
+    B = batch["state"].shape[1]
+    cfg = O.load_config(args.config, **over)
+    n_done, worst_steer, worst_acc, t_solve = 0, 0.0, 0.0, 0.0
+    t0 = time.perf_counter()
+    while n_done < min(B, 4096) and (time.perf_counter() - t0) < 0.4 * budget:
+        i = n_done
+        cfg.yaw_low, cfg.yaw_high = float(batch["yaw_lo"][i]), float(batch["yaw_hi"][i])
+        if w_np is not None:
+            for q in range(12):
+                cfg.weights[q] = float(w_np[q, i])
+        ts = time.perf_counter()
+        st, o9, _, _, _ = O.mpc_solve(cfg, batch["state"][:, i], batch["coeffs"][:, i])
+        t_solve += time.perf_counter() - ts
+        if st == 0 and status[i] == 0:
+            worst_steer = max(worst_steer, abs(o9[6] - float(out_np[6, i])))
+            worst_acc = max(worst_acc, abs(o9[7] - float(out_np[7, i])))
+        n_done += 1
+    one = {"value": n_done / t_solve, "unit": "solves/s", "cores": 1, "kind": "port",
+           "sample": "first %d instances of the same batch, oracle/mpc_oracle.c (dense IPOPT-style interior point), 1 thread "
+                     "of %d host cores" % (n_done, os.cpu_count() or 0)}
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    per = max(4, int(one["value"] * 0.45 * budget))              # instances per worker for ~0.45 x budget of wall time
+    per = min(per, max(1, min(B, 8192) // cores))
+    jobs = []
+    for c in range(cores):
+        lo = c * per
+        sl = slice(lo, lo + per)
+        jobs.append((args.config, over, batch["state"][:, sl].copy(), batch["coeffs"][:, sl].copy(), batch["yaw_lo"][sl].copy(),
+                     batch["yaw_hi"][sl].copy(), None if w_np is None else w_np[:, sl].copy()))
+    ctx = mp.get_context("spawn")                                  # never fork a process that holds a GPU context
+    with ctx.Pool(cores) as pool:
+        pool.map(O.solve_chunk, [j[:2] + (j[2][:, :1], j[3][:, :1], j[4][:1], j[5][:1], None if j[6] is None else j[6][:, :1]) for j in jobs])   # start-up outside the clock
+        tw = time.perf_counter()
+        done = pool.map(O.solve_chunk, jobs)
+        wall = time.perf_counter() - tw
+    allc = {"value": sum(done) / wall, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d instances of the same batch in %d worker processes (one oracle thread each) on the %d cores this "
+                      "process may use" % (sum(done), cores, cores)}
+    return one, allc, worst_steer, worst_acc, n_done
+
+
+def main():
+    args = parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1:
+        sys.exit(spawn_ranks(args))                                # before anything touches the GPU
 
     import numpy as np
     import torch
@@ -66,17 +165,23 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus)
-    if not torch.cuda.is_available():
+    stub = None
+    if args.stub:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_stub                                          # test infrastructure, never the product path
+        stub = bench_stub.make(args.stub, pkg)
+    if stub is None and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.single_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub is None:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -93,12 +198,22 @@ def main():
     if args.dt:
         over["dt"] = args.dt
     params = pkg.params_from_json(os.path.join(golden, args.config), **over)
+    f32 = args.precision == "f32"
+    if f32:
+        params.precision = pkg.PRECISION_F32
+    tdt = torch.float32 if f32 else torch.float64
     wp = pkg.scenarios.load_waypoints(os.path.join(golden, "lake_track_waypoints.csv"))
-    B = args.batch
+    if args.scaling == "strong":
+        G_total = args.global_batch or args.batch
+        if G_total % world:
+            raise SystemExit("--global-batch %d is not divisible by %d ranks" % (G_total, world))
+        B = G_total // world
+    else:
+        B = args.batch
     want_traj = not args.no_traj
-    # weak scaling: every rank draws its own instances (rank-specific PRNG stream)
-    batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # every rank draws its own instances (rank-specific PRNG stream)
+    batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank, filtered=not args.unfiltered)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=tdt)
     d_state, d_coef, d_ylo, d_yhi = t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"])
     w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank) if args.weights_sweep else None
     d_w = t(w_np) if w_np is not None else None
@@ -106,27 +221,32 @@ def main():
     # (25 iterations) while the average wave is done after ~70 % of that time; a second handle on a second stream lets
     # the next batch's waves take the SIMDs as they become free (measured: 2.2 -> 1.5 ms per batch).
     nfl = max(1, args.inflight)
-    mpcs = [pkg.BatchedMPC(params, B, device=local_rank) for _ in range(nfl)]
-    mpc = mpcs[0]
+    make = (lambda: stub.BatchedMPC(params, B)) if stub else (lambda: pkg.BatchedMPC(params, B, device=local_rank))
+    mpcs = [make() for _ in range(nfl)]
     # results go straight into a packed buffer that is gathered with one all_gather_into_tensor; two buffer sets
     # alternate so that the gather of batch i overlaps the solve of batch i+1 (sharding.PackedGather)
     pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
-                                   slots=max(2, nfl))
-    outs = pg.outputs(0)
+                                   slots=max(2, nfl), dtype=tdt)
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        if stub is None:
+            torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if stub is None:
+                torch.cuda.synchronize(dev)
 
     nstep = 0
+
+    class _NullCtx:
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
 
     def step(ev=None):
         nonlocal nstep
         slot = nstep % pg.slots
         h = mpcs[nstep % nfl]
-        with torch.cuda.stream(streams[nstep % nfl]):
+        with (torch.cuda.stream(streams[nstep % nfl]) if stub is None else _NullCtx()):
             pg.wait(slot)                               # the gather that last read this buffer set has finished
             if ev is not None:
                 ev[0].record()
@@ -139,18 +259,20 @@ def main():
     # The solves run on a high-priority stream: when a batch's gather (RCCL's own stream, normal priority) and the next
     # batch's solve become ready together, the solve's 1 024 waves are placed first and the collective's workgroups take
     # the SIMDs the solve frees in its tail, instead of holding SIMDs that 512-register waves cannot share.
-    torch.cuda.synchronize(dev)
-    streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(nfl)]
+    streams = None
+    if stub is None:
+        torch.cuda.synchronize(dev)
+        streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(nfl)]
     for _ in range(args.warmup):
         step()
     pg.finish()
     sync_all()
     # HIP events on the stream the kernel is launched on: torch's current stream, whose handle is what
     # solve_torch passes to mpc_solve_batch_device (a NULL handle is HIP's null stream = torch's default)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if stub is None else None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(ev[i])
+        step(ev[i] if ev else None)
     pg.finish()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -158,18 +280,19 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [a.elapsed_time(b) for a, b in ev] if ev else [1e3 * elapsed / args.steps]
     kernel_ms_avg = float(np.mean(kernel_ms))
     stats = mpcs[(nstep - 1) % nfl].stats()
     last = (nstep - 1) % pg.slots
     # the same launch alone on the device (nothing else in flight), for reference
     iso = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(streams[0]):
-            e0.record(); mpcs[0].solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(0)); e1.record()
-        torch.cuda.synchronize(dev)
-        iso.append(e0.elapsed_time(e1))
+    if stub is None:
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(streams[0]):
+                e0.record(); mpcs[0].solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(0)); e1.record()
+            torch.cuda.synchronize(dev)
+            iso.append(e0.elapsed_time(e1))
     outs = pg.outputs(last)
     status = outs["status"].cpu().numpy()
     out_np = outs["out"].cpu().numpy()
@@ -185,80 +308,107 @@ def main():
             dist.barrier(); dist.destroy_process_group()
         return
 
+    dtype = "f32" if f32 else "f64"
     total_solves = B * world * args.steps
     value = total_solves / elapsed
     mean_iters = stats.iter_sum / max(1, stats.batch)
     stages = params.N - 1
+    is_headline = (params.N == 10 and not args.weights_sweep and B == 65536 and not f32 and args.config == "config-fast.json" and want_traj)
     res = {
-        "metric": "MPC solves/sec (batch) at N=%d dt=%g" % (params.N, params.dt),
+        "metric": "%sMPC solves/sec (batch) at N=%d dt=%g" % ("STUB (not a measurement) " if stub else "", params.N, params.dt),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s%d lake-track states per GPU, 100 ms latency compensation, N=%d dt=%g, %s, trajectories %s%s"
-                               % ("BASELINE.json configs[2]: " if (params.N == 10 and not args.weights_sweep and B == 65536) else "",
-                                  B, params.N, params.dt, args.config, "on" if want_traj else "off",
-                                  ", per-instance weight sweep" if args.weights_sweep else ""),
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "%s%d lake-track states per GPU, 100 ms latency compensation, N=%d dt=%g, %s, trajectories %s%s%s"
+                               % ("BASELINE.json configs[2]: " if is_headline else "", B, params.N, params.dt, args.config,
+                                  "on" if want_traj else "off", ", per-instance weight sweep" if args.weights_sweep else "",
+                                  ", MPC_PRECISION_F32" if f32 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
-                   "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch%s"
-                                  % (world, ", overlapped with the next batch's solve" if (pg.overlap) else ""),
-                   "gather_checked": gather_ok, "batches_in_flight": nfl,
-                   "branch_mode": "frozen", "tol": params.tol, "max_iter": params.max_iter},
+                   "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch" % world,
+                   "collective_mode": pg.mode, "gather_checked": gather_ok, "batches_in_flight": nfl,
+                   "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
+                   "termination_polish": bool(params.polish),
+                   # the generator redraws instances the reference's own road model does not hold for (scenarios.py)
+                   "instance_filter": ("none (unfiltered draws)" if args.unfiltered else
+                                       "rejection sampling, %d draws for %d instances" % (batch["drawn"], B)),
+                   "instance_filter_rejected": batch["rejected"]},
         "converged_fraction": float((status == 0).mean()),
         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
         "mean_iterations": mean_iters, "max_iterations": int(stats.iter_max),
     }
-    per_solve = 8 * (6 + 5 + 2) + 8 * 9 + (8 * 2 * params.N if want_traj else 0) + (8 * 12 if args.weights_sweep else 0)
+    if stub:
+        res["stub"] = "%s: CPU build of the solver header, test infrastructure only" % args.stub
+    esz = 4 if f32 else 8
+    per_solve = esz * (6 + 5 + 2) + esz * 9 + (esz * 2 * params.N if want_traj else 0) + (esz * 12 if args.weights_sweep else 0)
     algo_bytes = per_solve * B
     achieved_gbs = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
-    if os.path.exists(pmc):
+    traffic, traffic_source = None, None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not name.endswith("pmc_traffic.json"):
+            continue
         try:
-            pj = json.load(open(pmc))
-            if pj.get("batch") == B and pj.get("config") == args.config and params.N == 10 and not args.weights_sweep and want_traj:
-                traffic = pj.get("hbm_bytes_per_launch")
+            pj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
-            traffic = None
+            continue
+        for e in pj.get("entries", [pj]):
+            if (e.get("batch") == B and e.get("config") == args.config and e.get("N", 10) == params.N and e.get("dtype", "f64") == dtype
+                    and bool(e.get("weights_sweep", False)) == bool(args.weights_sweep) and bool(e.get("traj", True)) == want_traj):
+                traffic = e.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/%s: rocprofv3 PMC passes of this workload on another run (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" % name
+                break
+        if traffic is not None:
+            break
+    flops_per_step = B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3
+    step_s = elapsed / args.steps
     res["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                       "kernel": "mpc_solve_kernel", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
-                       "kernel_ms_alone": float(np.median(iso)),
+                       "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                       "kernel": "mpc_solve_kernel<%s>" % ("float" if f32 else "double"),
+                       "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
+                       "kernel_ms_alone": float(np.median(iso)) if iso else None,
                        "algorithmic_bytes_per_launch": algo_bytes,
-                       "note": "fp64-VALU/latency-bound path: HBM fraction is small by construction (SURVEY.md 8d); "
-                               "kernel_ms_avg is the duration of a launch that shares the device with the other batch in flight, "
+                       # against the STEP time: with several batches in flight launches overlap, so a launch lasts longer than a step
+                       "frac_vs_step": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                       # what the kernel really streams (workspace) per step against the HBM peak -- the limit it sits on
+                       "traffic_gbs_vs_step": (traffic / step_s / 1e9) if traffic else None,
+                       "traffic_frac_of_hbm_peak": (traffic / step_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                       "note": "algorithmic bytes are tiny against the arithmetic (SURVEY.md 8d), so `frac` is small by construction; the "
+                               "kernel is balanced between instruction issue and the workspace it streams per sweep (`traffic`, DESIGN.md "
+                               "section 5); kernel_ms_avg is a launch that shares the device with the other batches in flight, "
                                "kernel_ms_alone the same launch by itself",
-                       # whole-device rate of this rank: with several batches in flight a launch shares the SIMDs, so the
-                       # flop rate is taken over the timed region, not over one launch's duration
-                       "fp64_valu_tflops": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (elapsed / args.steps) / 1e12,
-                       "fp64_valu_frac": B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3 / (elapsed / args.steps) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+                       "valu_tflops": flops_per_step / step_s / 1e12,
+                       "valu_frac": flops_per_step / step_s / 1e12 / VALU_PEAK_TFLOPS[dtype], "valu_peak_tflops": VALU_PEAK_TFLOPS[dtype]}
 
-    if world == 1 and not args.no_cpu_baseline:
-        # the checker, timed as the CPU baseline: oracle = plain-C restatement of the reference algorithm
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        cfg = O.load_config(args.config, **over)
-        n_done, worst_steer, worst_acc, t_cpu0 = 0, 0.0, 0.0, time.perf_counter()
-        t_solve = 0.0
-        while n_done < min(B, 4096) and (time.perf_counter() - t_cpu0) < args.cpu_seconds:
-            i = n_done
-            cfg.yaw_low, cfg.yaw_high = float(batch["yaw_lo"][i]), float(batch["yaw_hi"][i])
-            if w_np is not None:
-                for q in range(12):
-                    cfg.weights[q] = float(w_np[q, i])
-            ts = time.perf_counter()
-            st, o9, _, _, _ = O.mpc_solve(cfg, batch["state"][:, i], batch["coeffs"][:, i])
-            t_solve += time.perf_counter() - ts
-            if st == 0 and status[i] == 0:
-                worst_steer = max(worst_steer, abs(o9[6] - out_np[6, i]))
-                worst_acc = max(worst_acc, abs(o9[7] - out_np[7, i]))
-            n_done += 1
-        res["cpu_baseline"] = {"value": n_done / t_solve, "unit": "solves/s", "cores": 1, "kind": "port",
-                               "sample": "first %d instances of the same batch, oracle/mpc_oracle.c (dense IPOPT-style "
-                                         "interior point), 1 thread of %d host cores" % (n_done, os.cpu_count() or 0)}
+    if world == 1 and stub is None and not args.no_host_leg:
+        # PCIe-inclusive: the same batch from pageable host arrays through mpc_solve_batch_host (fp64 entry point)
+        if not f32:
+            hs = []
+            for _ in range(3):
+                th = time.perf_counter()
+                rh = mpcs[0].solve_numpy(batch["state"], batch["coeffs"], batch["yaw_lo"], batch["yaw_hi"], weights=w_np, want_traj=want_traj)
+                hs.append(time.perf_counter() - th)
+            host_ok = bool(np.array_equal(rh["out"], out_np) and np.array_equal(rh["status"], status))
+            p1 = params.copy()
+            with pkg.BatchedMPC(p1, 1, device=local_rank) as m1:
+                one = [a[..., :1].copy() for a in (batch["state"], batch["coeffs"], batch["yaw_lo"], batch["yaw_hi"])]
+                lat = []
+                for _ in range(60):
+                    th = time.perf_counter(); r1 = m1.solve_numpy(*one, want_traj=want_traj); lat.append(time.perf_counter() - th)
+                k1 = m1.stats().kernel_ms
+            res["host_path"] = {"entry": "mpc_solve_batch_host (pageable host arrays, one pinned staging copy each way)",
+                                "solves_per_s_incl_pcie": B / float(np.median(hs)), "ms_per_batch": 1e3 * float(np.median(hs)),
+                                "matches_device_path_bitwise": host_ok,
+                                "b1_latency_ms_median": 1e3 * float(np.median(lat[10:])), "b1_latency_ms_min": 1e3 * float(np.min(lat[10:])),
+                                "b1_kernel_ms": k1, "b1_iterations": int(r1["iters"][0]),
+                                "b1_note": "one MPC::solve() per telemetry message is what the reference does (mpc_main.cpp:167); includes the ctypes call"}
+    if world == 1 and stub is None and not args.no_cpu_baseline:
+        one, allc, worst_steer, worst_acc, n_done = cpu_baseline_legs(args, batch, w_np, over, status, out_np, args.cpu_seconds)
+        res["cpu_baseline"] = one
+        res["cpu_baseline_all_cores"] = allc
         res["max_abs_dsteer_vs_oracle"] = worst_steer
         res["max_abs_daccel_vs_oracle"] = worst_acc
         res["parity_sample"] = n_done
     print(json.dumps(res))
+    sys.stdout.flush()
     for h in mpcs:
         h.close()
     if dist is not None:

@@ -13,6 +13,7 @@ NSTATE = 6
 NOUT = 9
 MAX_N = 64
 ABI_VERSION = 2
+PRECISION_F64, PRECISION_F32 = 0, 1
 
 STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric"}
 ERR_NAMES = {0: "MPC_OK", -1: "MPC_ERR_INVALID", -2: "MPC_ERR_NO_DEVICE", -3: "MPC_ERR_HIP",
@@ -58,7 +59,8 @@ class MpcBatchStats(C.Structure):
 EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_params", "mpc_destroy",
            "mpc_last_error", "mpc_abi_version", "mpc_solve_batch_device", "mpc_solve_batch_host",
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
-           "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext"]
+           "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
+           "mpc_solve_batch_device_f32"]
 
 _lib = None
 
@@ -103,6 +105,7 @@ def library():
     L.mpc_abi_version.restype = C.c_int
     L.mpc_solve_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9 + [C.c_void_p]
     L.mpc_solve_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9
+    L.mpc_solve_batch_device_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9 + [C.c_void_p]
     L.mpc_synchronize.argtypes = [C.c_void_p]
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]
     L.mpc_debug_math.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 4

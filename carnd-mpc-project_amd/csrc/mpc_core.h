@@ -63,83 +63,100 @@
 namespace mpc {
 
 /* ---- workspace layout ------------------------------------------------------ */
-/* A "field" is one double per instance.  Stage k (0..N-2) owns:
+/* A "field" is one real per instance (R = double, or float for MPC_PRECISION_F32).  Stage k (0..N-2) owns:
  *   two iterate slots: s_{k+1} (6), u_k (2), lam_{k+1} (6), bound duals of (psi_{k+1}, v_{k+1}, delta_k, a_k) (4+4)
- *   the Newton direction  ds_{k+1} (6), du_k (2), dlam_{k+1} (6)
- *   the Riccati gains     K_k (2x6) and kff_k (2)   -- in LDS on the device when the launch allows it
+ *   the Newton direction  ds_{k+1} (6), du_k (2)
+ *   the Riccati gains     K_k (2x6) and kff_k (2)   -- in the iterate slot that is not current (see below)
  * Nothing else is kept: the stage model (sin/cos/atan, road polynomial, residual) is recomputed
  * in every sweep, because the kernel is limited by workspace traffic, not by arithmetic.
- * Everything is fp64: storing the direction or the gains in fp32 was tried and rejected -- an
+ * Fields move in GROUPS of 16 bytes per lane (G = 2 doubles or 4 floats): one global_load/store_dwordx4, one
+ * LDS-DMA piece.  The fp64 record is packed (22 fields = 11 groups); the fp32 record pads the multipliers to 8 so
+ * that every logical block starts on a group (24 fields = 6 groups).
+ * In the fp64 solver everything is fp64: storing the direction or the gains in fp32 was tried and rejected -- an
  * absolute error of ~1e-8 in a step component is fatal next to slacks of ~1e-9 at active bounds
- * (+11 % iterations and a few non-converged instances on the 65 536-instance workload). */
-enum : int {
-  F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22,   /* one iterate slot */
-  IT0 = 0, IT1 = IT_SZ,                                            /* double-buffered iterate */
-  F_D = 2 * IT_SZ, D_N = 8,                                        /* direction (ds, du) */
-  STAGE_SZ_GLOBAL = F_D + D_N,                                     /* 52 fields per stage */
-  /* The Riccati gains K (2x6) and kff (2) live only between the backward and the forward sweep of one pass, while
-   * the iterate slot that is not the current one holds nothing (the next trial point is written there afterwards):
-   * they are stored in the first 14 fields of that slot.  The workspace is a fifth smaller for it, and the
-   * workspace stream does live in the caches (bypassing them costs 40 %). */
-  F_GK = 0, GK_N = 12, F_GF = F_GK + GK_N, GF_N = 2
+ * (+11 % iterations and a few non-converged instances on the 65 536-instance workload).  The fp32 solver
+ * (MPC_PRECISION_F32) runs to a tolerance of 1e-4 with a barrier floor of 1e-5, where fp32 steps are adequate. */
+template <class R> struct Layout;
+template <> struct Layout<double> { enum : int { G = 2, F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22 }; };
+template <> struct Layout<float> { enum : int { G = 4, F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 16, F_ZU = 20, IT_SZ = 24 }; };
+template <class R> struct Fields : Layout<R> {
+  using L = Layout<R>;
+  enum : int {
+    IT0 = 0, IT1 = L::IT_SZ,                                   /* double-buffered iterate */
+    F_D = 2 * L::IT_SZ, D_N = 8,                               /* direction (ds, du) */
+    STAGE_SZ = F_D + D_N,                                      /* fields per stage: 52 (fp64), 56 (fp32) */
+    /* The Riccati gains K (2x6) and kff (2) live only between the backward and the forward sweep of one pass, while
+     * the iterate slot that is not the current one holds nothing (the next trial point is written there afterwards):
+     * they are stored in the first fields of that slot.  The workspace is a fifth smaller for it, and the
+     * workspace stream does live in the caches (bypassing them costs 40 %). */
+    F_GK = 0, GK_N = 12, F_GF = F_GK + GK_N, GF_N = 2, GAIN_SZ = (GK_N + GF_N + L::G - 1) / L::G * L::G,
+    D_S = 0, D_U = 6,                                          /* direction entries */
+    /* Staging interface (see TiledWorkspace): a sweep asks for the record of the NEXT stage while it works on the
+     * current one.  stage_fetch_it copies the iterate slot of stage k to the front of buffer `buf`, stage_fetch_g /
+     * stage_fetch_d the gains or the direction behind it; sit()/sg()/sx() read them back; stage_wait<N>() waits until
+     * at most the N most recent copy/store instructions are still in flight.  Counts are in 16-byte groups. */
+    STG_IT_OPS = L::IT_SZ / L::G, STG_ITF_OPS = 16 / L::G, STG_X_OPS = GAIN_SZ / L::G, STG_D_OPS = D_N / L::G,
+    STG_SLOT = STG_IT_OPS + (STG_X_OPS > STG_D_OPS ? STG_X_OPS : STG_D_OPS),
+    /* group stores a stage issues in each sweep (all through store_run): the counted waits let exactly these
+     * stay in flight besides the newest copy group */
+    ST_BACKWARD = GAIN_SZ / L::G, ST_FORWARD = D_N / L::G, ST_TRIAL = L::IT_SZ / L::G
+  };
+  static_assert((int)GAIN_SZ <= (int)L::IT_SZ, "the gains must fit an iterate slot");
+  static_assert(L::F_ZL % L::G == 0 && L::F_ZU == L::F_ZL + 4 && L::F_U == L::F_S + 6, "blocks the forward sweep fetches");
 };
-static_assert(GK_N + GF_N <= IT_SZ, "the gains must fit an iterate slot");
-enum : int { D_S = 0, D_U = 6 };                                   /* direction entries */
 
-MPC_HD int64_t workspace_fields_per_instance(int N, bool) { return (int64_t)(N - 1) * STAGE_SZ_GLOBAL; }
-
-/* Staging interface (see TiledWorkspace): a sweep asks for the record of the NEXT stage while it works on the
- * current one.  stage_fetch_it copies the IT_SZ fields of an iterate slot of stage k to the front of buffer `buf`,
- * stage_fetch_g / stage_fetch_d the gains or the direction behind it; sit()/sg()/sx() read them back; stage_wait<N>()
- * waits until at most the N most recent copy/store instructions are still in flight.  On the host build all of
- * this degenerates to direct reads. */
-enum : int { STG_IT_OPS = IT_SZ / 2, STG_ITF_OPS = 8, STG_X_OPS = 7, STG_D_OPS = D_N / 2, STG_SLOT_PAIRS = (IT_SZ + 14) / 2 };
-/* pair stores a stage issues in each sweep (all through store2): the counted waits let exactly these
- * stay in flight besides the newest copy group */
-enum : int { ST_BACKWARD = (GK_N + GF_N) / 2, ST_FORWARD = 4, ST_TRIAL = IT_SZ / 2 };
+MPC_HD int64_t workspace_fields_per_instance(int N, bool f32) { return (int64_t)(N - 1) * (f32 ? (int)Fields<float>::STAGE_SZ : (int)Fields<double>::STAGE_SZ); }
 
 /* Plain storage for the test-only host build: one instance, fields contiguous. */
+template <class R>
 struct HostWorkspace {
-  double *base;
+  using F = Fields<R>;
+  R *base;
   /* field f of iterate slot I (or I = 0 and an absolute field) of stage k */
-  MPC_HD double &it(int k, int I, int f) const { return base[k * STAGE_SZ_GLOBAL + I + f]; }
-  MPC_HD double getD(int k, int j) const { return base[k * STAGE_SZ_GLOBAL + F_D + j]; }
-  MPC_HD void setD(int k, int j, double v) const { base[k * STAGE_SZ_GLOBAL + F_D + j] = v; }
-  MPC_HD void store2(int k, int I, int f, double a, double b) const { base[k * STAGE_SZ_GLOBAL + I + f] = a; base[k * STAGE_SZ_GLOBAL + I + f + 1] = b; }
+  MPC_HD R &it(int k, int I, int f) const { return base[k * F::STAGE_SZ + I + f]; }
+  MPC_HD R getD(int k, int j) const { return base[k * F::STAGE_SZ + F::F_D + j]; }
+  MPC_HD void setD(int k, int j, R v) const { base[k * F::STAGE_SZ + F::F_D + j] = v; }
+  template <int F0, int COUNT> MPC_HD void store_run(int k, int I, const R *v) const {
+    for (int j = 0; j < COUNT; j++) base[k * F::STAGE_SZ + I + F0 + j] = v[j];
+  }
   MPC_HD void stage_fetch_it(int, int, int) const {}
   MPC_HD void stage_fetch_itf(int, int, int) const {}
   MPC_HD void stage_fetch_d(int, int) const {}
   template <int N> MPC_HD void stage_wait() const {}
   MPC_HD void stage_drain() const {}
-  MPC_HD double sit(int, int k, int I, int j) const { return base[k * STAGE_SZ_GLOBAL + I + j]; }
-  MPC_HD double sx(int, int k, int F, int j) const { return base[k * STAGE_SZ_GLOBAL + F + j]; }
+  MPC_HD R sit(int, int k, int I, int j) const { return base[k * F::STAGE_SZ + I + j]; }
+  MPC_HD R sx(int, int k, int Fo, int j) const { return base[k * F::STAGE_SZ + Fo + j]; }
   MPC_HD void stage_fetch_g(int, int, int) const {}
-  MPC_HD double sg(int, int k, int J, int j) const { return base[k * STAGE_SZ_GLOBAL + J + j]; }
+  MPC_HD R sg(int, int k, int J, int j) const { return base[k * F::STAGE_SZ + J + F::F_GK + j]; }
 };
 
 #if defined(__HIPCC__)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(3))) char lchar;
 #else   /* host pass of hipcc: the kernel body is parsed but never run */
 typedef double gdouble;
+typedef float gfloat;
 typedef char gchar;
 typedef double ldouble;
+typedef float lfloat;
 typedef char lchar;
 #endif
 /* Device layout: the workspace is tiled per wavefront and, inside a tile, fields are interleaved in
- * PAIRS per lane:  [wave][stage][field pair][64 lanes][2].  One wave's whole working set is one
- * contiguous block (N=10: 72 x 9 x 512 B = 324 KB), and the two fields of a pair of one instance are 16
- * contiguous bytes, so
- *   - a pair moves with one 16-byte-per-lane access (global_load/store_dwordx4: the coalescing sweet spot),
+ * GROUPS of 16 bytes per lane:  [wave][stage][group][64 lanes][G], G = 2 doubles or 4 floats.  One wave's
+ * whole working set is one contiguous block (fp64, N=10: 26 x 9 x 1 KB = 234 KB), and the fields of a group of
+ * one instance are 16 contiguous bytes, so
+ *   - a group moves with one 16-byte-per-lane access (global_load/store_dwordx4: the coalescing sweet spot),
  *   - `global_load_lds_dwordx4` (LDS-DMA) moves each lane's OWN data, which keeps it correct under the
  *     partial exec masks of a wave whose instances are in different solver phases.
  * Each sweep double-buffers the next stage's record into LDS with LDS-DMA while it computes the current
  * stage: the kernel needs all 512 registers (one wave per SIMD), so nothing else can hide the
  * HBM / Infinity-Cache latency, and a register prefetch does not fit (it spilled 428 VGPRs).
- * LDS: 2 buffers x 36 fields x 512 B = 36 KB per wave, 144 KB per CU at four waves.
+ * LDS: 2 buffers x 18 groups x 1 KB = 36 KB per wave in fp64 (144 KB per CU at four waves), 2 x 10 x 1 KB = 20 KB in fp32.
  * All pointers are typed into their address space: accesses are global_* / ds_* instructions, never flat_*;
  * the tile base is wave-uniform and byte offsets are formed in 32 bits (saddr + voffset addressing). */
 /* Addressing: the byte offset of (stage k, field) is wave-uniform and goes through the scalar unit into the
@@ -159,45 +176,59 @@ __device__ __forceinline__ unsigned mpc_uniform(unsigned x) {
 #else
 #define MPC_UNIFORM(x) ((unsigned)(x))
 #endif
-template <bool STAGING>
+template <class R> struct AddrSpace;
+template <> struct AddrSpace<double> { typedef gdouble g; typedef ldouble l; };
+template <> struct AddrSpace<float> { typedef gfloat g; typedef lfloat l; };
+
+template <bool STAGING, class R>
 struct TiledWorkspace {
-  gdouble *tile;   /* this wave's tile */
-  ldouble *lbuf;   /* LDS staging area of this wave (STAGING) */
+  using F = Fields<R>;
+  typedef typename AddrSpace<R>::g greal;
+  typedef typename AddrSpace<R>::l lreal;
+  greal *tile;   /* this wave's tile */
+  lreal *lbuf;   /* LDS staging area of this wave (STAGING) */
   int lane;
-  static constexpr unsigned STAGE = STAGE_SZ_GLOBAL;
-  static constexpr unsigned PAIRS = STAGE_SZ_GLOBAL / 2;
-  /* uniform part: row of (stage k, field f) + position inside the pair; vector part: lane and slot */
+  static constexpr unsigned G = F::G;
+  static constexpr unsigned GROUPS = F::STAGE_SZ / F::G;    /* 16-byte groups per stage */
+  static_assert(F::STAGE_SZ % F::G == 0 && F::IT_SZ % F::G == 0, "whole groups");
+  /* uniform part: row of (stage k, field f) + position inside the group; vector part: lane and slot */
   MPC_HD gchar *row(int k, int f) const {
-    return (gchar *)tile + MPC_UNIFORM(((unsigned)k * PAIRS + ((unsigned)f >> 1)) * 1024u + ((unsigned)f & 1u) * 8u);
+    return (gchar *)tile + MPC_UNIFORM(((unsigned)k * GROUPS + ((unsigned)f / G)) * 1024u + ((unsigned)f % G) * (unsigned)sizeof(R));
   }
-  MPC_HD unsigned voff(int I) const { return (unsigned)lane * 16u + ((unsigned)I >> 1) * 1024u; }
-  MPC_HD gdouble &it(int k, int I, int f) const { return *(gdouble *)(row(k, f) + voff(I)); }
-  /* both fields of a pair (f even) with ONE 16-byte store: the number of store instructions per stage is
-   * then exact, which the counted waits of the staged sweeps rely on */
-  MPC_HD void store2(int k, int I, int f, double a, double b) const {
-    typedef double __attribute__((ext_vector_type(2))) d2;
-    typedef __attribute__((address_space(1))) d2 gd2;
-    d2 v; v.x = a; v.y = b;
-    *(gd2 *)(row(k, f) + voff(I)) = v;
+  MPC_HD unsigned voff(int I) const { return (unsigned)lane * 16u + ((unsigned)I / G) * 1024u; }
+  MPC_HD greal &it(int k, int I, int f) const { return *(greal *)(row(k, f) + voff(I)); }
+  /* COUNT fields from field F0 (both multiples of G) with ONE 16-byte store per group: the number of store
+   * instructions per stage is then exact, which the counted waits of the staged sweeps rely on */
+  template <int F0, int COUNT> MPC_HD void store_run(int k, int I, const R *v) const {
+    static_assert(F0 % F::G == 0 && COUNT % F::G == 0, "whole groups");
+    typedef R __attribute__((ext_vector_type(16 / sizeof(R)))) vec;
+    typedef __attribute__((address_space(1))) vec gvec;
+    MPC_UNROLL
+    for (int g = 0; g < COUNT / (int)G; g++) {
+      vec x;
+      MPC_UNROLL
+      for (int e = 0; e < (int)G; e++) x[e] = v[g * (int)G + e];
+      *(gvec *)(row(k, F0 + g * (int)G) + voff(I)) = x;
+    }
   }
-  MPC_HD double getD(int k, int j) const { return it(k, 0, F_D + j); }
-  MPC_HD void setD(int k, int j, double v) const { it(k, 0, F_D + j) = v; }
+  MPC_HD R getD(int k, int j) const { return it(k, 0, F::F_D + j); }
+  MPC_HD void setD(int k, int j, R v) const { it(k, 0, F::F_D + j) = v; }
   /* ---- staging ---- */
-  /* Copies NPAIRS consecutive pairs.  Rows are 1 KB apart in the tile AND in the LDS slot, and the
+  /* Copies NG consecutive groups.  Rows are 1 KB apart in the tile AND in the LDS slot, and the
    * instruction's immediate offset applies to both addresses, so four copies share one scalar row base and
    * one M0 value (immediates 0, 1024, 2048, 3072).  Written as assembly because the compiler expands the
    * builtin's offset argument back into per-copy address arithmetic (5 issue slots per copy instead of <2).
    * The compiler does not see these as memory instructions; that only makes its own vmcnt waits more
    * conservative (vmcnt completes in order), and the sweeps order everything staged with explicit waits. */
-  template <int NPAIRS>
-  MPC_HD void dma(int buf, int k, int I, int f0, int dst_pair) const {
+  template <int NG>
+  MPC_HD void dma(int buf, int k, int I, int f0, int dst_group) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned vo = voff(I);
     MPC_UNROLL
-    for (int q0 = 0; q0 < NPAIRS; q0 += 4) {
-      const unsigned m0v = MPC_UNIFORM((unsigned)(unsigned long)lbuf + (((unsigned)buf * STG_SLOT_PAIRS + (unsigned)dst_pair + (unsigned)q0) * 64u) * 16u);
-      const gchar *src = row(k, f0 + 2 * q0);
-      constexpr int n = (NPAIRS - 0);
+    for (int q0 = 0; q0 < NG; q0 += 4) {
+      const unsigned m0v = MPC_UNIFORM((unsigned)(unsigned long)lbuf + (((unsigned)buf * F::STG_SLOT + (unsigned)dst_group + (unsigned)q0) * 64u) * 16u);
+      const gchar *src = row(k, f0 + (int)G * q0);
+      constexpr int n = (NG - 0);
       if (q0 + 4 <= n)
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
@@ -214,14 +245,14 @@ struct TiledWorkspace {
     }
 #endif
   }
-  MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<STG_IT_OPS>(buf, k, I, 0, 0); }
+  MPC_HD void stage_fetch_it(int buf, int k, int I) const { if (STAGING) dma<F::STG_IT_OPS>(buf, k, I, 0, 0); }
   /* the forward sweep does not read the multipliers: (s, u) and the bound duals go to their usual places */
   MPC_HD void stage_fetch_itf(int buf, int k, int I) const {
-    if (STAGING) { dma<4>(buf, k, I, F_S, F_S / 2); dma<4>(buf, k, I, F_ZL, F_ZL / 2); }
+    if (STAGING) { dma<8 / F::G>(buf, k, I, F::F_S, F::F_S / F::G); dma<8 / F::G>(buf, k, I, F::F_ZL, F::F_ZL / F::G); }
   }
-  MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<STG_D_OPS>(buf, k, 0, F_D, STG_IT_OPS); }
+  MPC_HD void stage_fetch_d(int buf, int k) const { if (STAGING) dma<F::STG_D_OPS>(buf, k, 0, F::F_D, F::STG_IT_OPS); }
   /* the gains, in the first fields of iterate slot J (the one that is not current) */
-  MPC_HD void stage_fetch_g(int buf, int k, int J) const { if (STAGING) dma<STG_X_OPS>(buf, k, J, F_GK, STG_IT_OPS); }
+  MPC_HD void stage_fetch_g(int buf, int k, int J) const { if (STAGING) dma<F::STG_X_OPS>(buf, k, J, F::F_GK, F::STG_IT_OPS); }
   /* Between sweeps: a sweep's first copies read what the sweep before it stored, so all earlier stores of the
    * wave are waited for first.  (Vector memory operations of one wave are performed in order, and with
    * -DMPC_NO_DRAIN the results stay bitwise identical; the wait costs nothing measurable -- same-box A/B 2.02 vs
@@ -236,12 +267,12 @@ struct TiledWorkspace {
     if (STAGING) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
   }
-  MPC_HD double sl(int buf, int j) const {
-    return lbuf[(((unsigned)buf * STG_SLOT_PAIRS + ((unsigned)j >> 1)) * 64u + (unsigned)lane) * 2u + ((unsigned)j & 1u)];
+  MPC_HD R sl(int buf, int j) const {
+    return lbuf[(((unsigned)buf * F::STG_SLOT + ((unsigned)j / G)) * 64u + (unsigned)lane) * G + ((unsigned)j % G)];
   }
-  MPC_HD double sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (double)it(k, I, j); }
-  MPC_HD double sx(int buf, int k, int F, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, 0, F + j); }
-  MPC_HD double sg(int buf, int k, int J, int j) const { return STAGING ? sl(buf, IT_SZ + j) : (double)it(k, J, F_GK + j); }
+  MPC_HD R sit(int buf, int k, int I, int j) const { return STAGING ? sl(buf, j) : (R)it(k, I, j); }
+  MPC_HD R sx(int buf, int k, int Fo, int j) const { return STAGING ? sl(buf, F::IT_SZ + j) : (R)it(k, 0, Fo + j); }
+  MPC_HD R sg(int buf, int k, int J, int j) const { return STAGING ? sl(buf, F::IT_SZ + j) : (R)it(k, J, F::F_GK + j); }
 };
 #endif
 
@@ -385,7 +416,96 @@ MPC_HD double flog(double x) {
   return dk * MPC_K(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * MPC_K(1.90821492927058770002e-10))) - f);
 }
 
+
+/* ---- single-precision versions (the MPC_PRECISION_F32 solver) ----------------------------------------------
+ * v_rcp_f32 is accurate to 1 ulp, so no Newton step; sin/cos: Cody-Waite reduction by pi/2 in three parts and
+ * polynomial kernels of degree 9/6 on [-pi/4, pi/4] (interpolants at Chebyshev nodes, |err| < 8e-8);
+ * atan: reciprocal for |x| > 1, odd polynomial of degree 19 on [0,1]; log: the hardware's log2. */
+MPC_HD float frcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+MPC_HD float frcp1(float x) { return frcp(x); }
+MPC_HD float hpow(float x, float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_exp2f(p * __builtin_log2f(fminf(x, 1e16f)));
+#else
+  return powf(x, p);
+#endif
+}
+MPC_HD void fsincos_finish(float r, float z, float ps, float pc, int q, float *sn, float *cs) {
+  const float s0 = fmaf(r * z, ps, r);
+  const float c0 = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const float s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+MPC_HD void fsincos2(float xa, float xb, float *sna, float *csa, float *snb, float *csb) {
+  if (!(fabsf(xa) < 1.0e4f)) xa = NAN;   /* the three-part reduction below is exact for quadrant counts < 2^13 */
+  if (!(fabsf(xb) < 1.0e4f)) xb = NAN;
+  const float ka = rintf(xa * 6.36619772e-01f), kb = rintf(xb * 6.36619772e-01f);
+  /* pi/2 = 1.5703125 + 4.83751297e-4 + 7.549789954e-8 (the first two parts have few mantissa bits: k * part is exact) */
+  float ra = fmaf(-ka, 1.5703125f, xa), rb = fmaf(-kb, 1.5703125f, xb);
+  ra = fmaf(-ka, 4.83751297e-4f, ra); rb = fmaf(-kb, 4.83751297e-4f, rb);
+  ra = fmaf(-ka, 7.549789954e-8f, ra); rb = fmaf(-kb, 7.549789954e-8f, rb);
+  const float za = ra * ra, zb = rb * rb;
+  float psa = 2.7249925803e-06f, psb = psa;
+#define MPC_H2F(pa, pb, k) do { pa = fmaf(za, pa, k); pb = fmaf(zb, pb, k); } while (0)
+  MPC_H2F(psa, psb, -1.9840086735e-04f);
+  MPC_H2F(psa, psb, 8.3333318747e-03f);
+  MPC_H2F(psa, psb, -1.6666666664e-01f);
+  float pca = 2.4547942085e-05f, pcb = pca;
+  MPC_H2F(pca, pcb, -1.3888303036e-03f);
+  MPC_H2F(pca, pcb, 4.1666664660e-02f);
+#undef MPC_H2F
+  fsincos_finish(ra, za, psa, pca, (int)ka & 3, sna, csa);
+  fsincos_finish(rb, zb, psb, pcb, (int)kb & 3, snb, csb);
+}
+MPC_HD void fsincos(float x, float *sn, float *cs) {
+  float s2, c2;
+  fsincos2(x, x, sn, cs, &s2, &c2);
+}
+MPC_HD float fatan(float x) {
+  const float ax = fabsf(x);
+  const bool inv = ax > 1.0f;
+  const float t = inv ? frcp(ax) : ax;
+  const float z = t * t;
+  /* atan(t) = t + t z q(z) on [0,1], q of degree 8 (interpolant at the Chebyshev nodes; total error 7e-8) */
+  float q = -2.3869973167e-03f;
+  q = fmaf(q, z, 1.3507771427e-02f);
+  q = fmaf(q, z, -3.5871538982e-02f);
+  q = fmaf(q, z, 6.2501694447e-02f);
+  q = fmaf(q, z, -8.6568804302e-02f);
+  q = fmaf(q, z, 1.1033764115e-01f);
+  q = fmaf(q, z, -1.4278568748e-01f);
+  q = fmaf(q, z, 1.9999739330e-01f);
+  q = fmaf(q, z, -3.3333331733e-01f);
+  float r = fmaf(t * z, q, t);
+  if (inv) r = 1.57079637e+00f - r;
+  return copysignf(r, x);
+}
+MPC_HD float flog(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_logf(x) * 6.93147182e-01f;   /* v_log_f32 = log2, 1 ulp */
+#else
+  return logf(x);
+#endif
+}
+/* conversions between the solver's real type and the fp64 pieces it keeps (road polynomial, merit sums) */
+MPC_HD double mpc_abs(double x) { return fabs(x); }
+MPC_HD float mpc_abs(float x) { return fabsf(x); }
+MPC_HD double mpc_max(double a, double b) { return fmax(a, b); }
+MPC_HD float mpc_max(float a, float b) { return fmaxf(a, b); }
+MPC_HD double mpc_min(double a, double b) { return fmin(a, b); }
+MPC_HD float mpc_min(float a, float b) { return fminf(a, b); }
+MPC_HD double mpc_sqrt(double a) { return sqrt(a); }
+MPC_HD float mpc_sqrt(float a) { return sqrtf(a); }
+
 /* IPOPT default constants (Waechter & Biegler 2006; IPOPT 3.12 option defaults) */
+template <class R>
 struct IpmConst {
 #ifndef MPC_KAPPA_MU
 #define MPC_KAPPA_MU 0.2
@@ -399,11 +519,12 @@ struct IpmConst {
 #ifndef MPC_TAU_MIN
 #define MPC_TAU_MIN 0.99
 #endif
-  static constexpr double kappa_eps = MPC_KAPPA_EPS, kappa_mu = MPC_KAPPA_MU, theta_mu = 1.5, tau_min = MPC_TAU_MIN, s_max = 100.0;
-  static constexpr double gamma_theta = 1e-5, gamma_phi = 1e-8, delta_sw = 1.0, s_theta = 1.1, s_phi = 2.3;
-  static constexpr double eta_phi = 1e-8, gamma_alpha = 0.05, kappa_sigma = 1e10, kappa1 = 1e-2, kappa2 = 1e-2;
-  static constexpr double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, kw_minus = 1.0 / 3.0, kw_plus = 8.0;
-  static constexpr double kw_plus_bar = 100.0, mu_init = MPC_MU_INIT, eps = 2.220446049250313e-16;
+  static constexpr R kappa_eps = MPC_KAPPA_EPS, kappa_mu = MPC_KAPPA_MU, theta_mu = 1.5, tau_min = MPC_TAU_MIN, s_max = 100.0;
+  static constexpr R gamma_theta = 1e-5, gamma_phi = 1e-8, delta_sw = 1.0, s_theta = 1.1, s_phi = 2.3;
+  static constexpr R eta_phi = 1e-8, gamma_alpha = 0.05, kappa_sigma = 1e10, kappa1 = 1e-2, kappa2 = 1e-2;
+  static constexpr R dw_min = 1e-20, dw_0 = 1e-4, dw_max = sizeof(R) == 8 ? 1e40 : 1e30, kw_minus = 1.0 / 3.0, kw_plus = 8.0;
+  static constexpr R kw_plus_bar = 100.0, mu_init = MPC_MU_INIT, eps = sizeof(R) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+  static constexpr R inv_kappa_sigma = 1.0 / 1e10, huge = sizeof(R) == 8 ? 1e300 : 1e37;
 };
 
 /* Vehicle::computeSpeedTarget, src/model/Vehicle.cpp:34-64 */
@@ -420,44 +541,55 @@ MPC_HD double speed_target(const MpcParams &P, double angle, double maxv) {
 }
 
 /* what a trial-point evaluation returns */
+template <class R>
 struct Eval {
-  double theta;  /* ||c||_1            */
-  double cinf;   /* ||c||_inf          */
-  double f;      /* unscaled objective without the stage-0 constant */
-  double L;      /* sum of log(slack)  */
-  double dinf;   /* ||grad_x Lagrangian||_inf (scaled objective) */
-  double cmin, cmax; /* range of slack*dual products */
-  double lsum, zsum; /* ||lam||_1, ||z||_1 */
-  double du0;        /* max(|d delta_0|, |d a_0|) of the direction this trial was made with (unscaled by alpha) */
+  R theta;  /* ||c||_1            */
+  R cinf;   /* ||c||_inf          */
+  R f;      /* unscaled objective without the stage-0 constant */
+  R L;      /* sum of log(slack)  */
+  R dinf;   /* ||grad_x Lagrangian||_inf (scaled objective) */
+  R cmin, cmax; /* range of slack*dual products */
+  R lsum, zsum; /* ||lam||_1, ||z||_1 */
+  R du0;        /* max(|d delta_0|, |d a_0|) of the direction this trial was made with (unscaled by alpha) */
   bool ok;
 };
 
 /* linearisation of one stage at (s_k, u_k) and its residual c_{k+1} = s_{k+1} - F(s_k, u_k) */
+template <class R>
 struct Lin {
-  double sp, cp, se, ce;   /* sin/cos of psi_k and epsi_k */
-  double fp, g1, h3, fpp;  /* f'(x_k), f''/(1+f'^2), d/dx of that, f'' */
-  double c[6];
+  R sp, cp, se, ce;   /* sin/cos of psi_k and epsi_k */
+  R fp, g1, h3, fpp;  /* f'(x_k), f''/(1+f'^2), d/dx of that, f'' */
+  R c[6];
 };
 
-template <class WS>
+template <class WS, class R>
 struct Solver {
+  using F = Fields<R>;
+  using IC = IpmConst<R>;
+  typedef Eval<R> EvalR;
+  typedef Lin<R> LinR;
+  static constexpr int F_S = F::F_S, F_U = F::F_U, F_LAM = F::F_LAM, F_ZL = F::F_ZL, F_ZU = F::F_ZU, IT_SZ = F::IT_SZ;
+  static constexpr int IT0 = F::IT0, IT1 = F::IT1, F_D = F::F_D, D_N = F::D_N, D_S = F::D_S, D_U = F::D_U;
+  static constexpr int F_GK = F::F_GK, GK_N = F::GK_N, F_GF = F::F_GF, GAIN_SZ = F::GAIN_SZ;
+  static constexpr int STG_IT_OPS = F::STG_IT_OPS, STG_ITF_OPS = F::STG_ITF_OPS, STG_X_OPS = F::STG_X_OPS, STG_D_OPS = F::STG_D_OPS;
+  static constexpr int ST_BACKWARD = F::ST_BACKWARD, ST_FORWARD = F::ST_FORWARD, ST_TRIAL = F::ST_TRIAL;
   const MpcParams &P;
   WS ws;
   /* instance data */
-  double st[6], coef[MPC_NCOEF], yl, yu;
-  double wc, we, wv, wd, wdd, vref, cost0;
+  R st[6], coef[MPC_NCOEF], yl, yu;
+  R wc, we, wv, wd, wdd, vref, cost0;
   /* bounds */
-  double vl, vu, dl, du, al, au;
+  R vl, vu, dl, du, al, au;
   int M;       /* number of stages = N-1 */
-  double dt, dtLf, iLf, psi_start;
+  R dt, dtLf, iLf, psi_start;
   /* interior-point state */
   int cur;     /* slot of the current iterate */
-  double mu, tau, df;
-  Eval E;
+  R mu, tau, df;
+  EvalR E;
   /* direction summary */
-  double amax, az, dphi, dxinf, xinf;
+  R amax, az, dphi, dxinf, xinf;
   /* filter: four entries in registers (it is emptied at every barrier update) */
-  double fth0, fth1, fth2, fth3, fph0, fph1, fph2, fph3;
+  R fth0, fth1, fth2, fth3, fph0, fph1, fph2, fph3;
   int nf;
   int iters, n_reg;
   /* true only while the least-squares multiplier start is being computed: the sweeps then solve
@@ -469,52 +601,62 @@ struct Solver {
   MPC_HD int it(int slot) const { return slot ? IT1 : IT0; }
 
   /* ---- road polynomial: RoadGeometry::centerY / orientation, utils.h:28-47 */
-  MPC_HD void poly(double x, double &f, double &fp, double &fpp, double &fppp) const {
+  /* Always evaluated in fp64, also by the fp32 solver: at x ~ 80 m the terms of a degree-4 Horner scheme reach
+   * ~1e7 times the size of the cte they are compared with; the cost is a dozen fp64 FMAs. */
+  MPC_HD void poly(R xr, R y, R &fmy, R &fp, R &fpp, R &fppp) const {   /* fmy = f(x) - y, the cte before the step */
+    const double x = xr;
     const double c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4];
-    f = (((c4 * x + c3) * x + c2) * x + c1) * x + c0;
-    fp = ((4.0 * c4 * x + 3.0 * c3) * x + 2.0 * c2) * x + c1;
-    fpp = (12.0 * c4 * x + 6.0 * c3) * x + 2.0 * c2;
-    fppp = 24.0 * c4 * x + 6.0 * c3;
+    fmy = (R)(((((c4 * x + c3) * x + c2) * x + c1) * x + c0) - (double)y);
+    fp = (R)(((4.0 * c4 * x + 3.0 * c3) * x + 2.0 * c2) * x + c1);
+    fpp = (R)((12.0 * c4 * x + 6.0 * c3) * x + 2.0 * c2);
+    fppp = (R)(24.0 * c4 * x + 6.0 * c3);
   }
 
   /* Stage model at (s,u), MPC.cpp:142-152, and the residual against the successor state sn.
    * Recomputed wherever it is needed (see the layout comment). */
-  MPC_HD void linearise(const double *s, double delta, double a, const double *sn, Lin &L) const {
+  MPC_HD void linearise(const R *s, R delta, R a, const R *sn, LinR &L) const {
     fsincos2(s[2], s[5], &L.sp, &L.cp, &L.se, &L.ce);
-    double f, fp, fpp, fppp;
-    poly(s[0], f, fp, fpp, fppp);
-    const double q1 = 1.0 + fp * fp, iq1 = frcp1(q1);
+    R fmy, fp, fpp, fppp;
+    poly(s[0], s[1], fmy, fp, fpp, fppp);
+    const R q1 = R(1.0) + fp * fp, iq1 = frcp1(q1);
     L.fp = fp;
     L.g1 = fpp * iq1;
-    L.h3 = (fppp * q1 - 2.0 * fp * fpp * fpp) * (iq1 * iq1);
+    L.h3 = (fppp * q1 - R(2.0) * fp * fpp * fpp) * (iq1 * iq1);
     L.fpp = fpp;
-    const double vdt = s[3] * dt;
-    const double psin = s[2] + delta * vdt * iLf;
-    L.c[0] = sn[0] - (s[0] + L.cp * vdt);
-    L.c[1] = sn[1] - (s[1] + L.sp * vdt);
+    const R vdt = s[3] * dt;
+    const R psin = s[2] + delta * vdt * iLf;
+    if (sizeof(R) == 8) {
+      L.c[0] = sn[0] - (s[0] + L.cp * vdt);
+      L.c[1] = sn[1] - (s[1] + L.sp * vdt);
+    } else {
+      /* fp32: first the difference of the two neighbouring states (exact, or nearly: they are close), then the
+       * increment -- x + v dt cos(psi) rounded at x ~ 80 m would cost 4e-6 m of residual */
+      L.c[0] = (sn[0] - s[0]) - L.cp * vdt;
+      L.c[1] = (sn[1] - s[1]) - L.sp * vdt;
+    }
     L.c[2] = sn[2] - psin;
     L.c[3] = sn[3] - (s[3] + a * dt);
-    L.c[4] = sn[4] - ((f - s[1]) + L.se * vdt);
+    L.c[4] = sn[4] - (fmy + L.se * vdt);
     L.c[5] = sn[5] - (psin - fatan(fp));
   }
 
   /* cost + barrier terms of one state s_k (k>=1): Hessian diagonal and gradient */
-  MPC_HD void state_terms(double psi, double v, double c, double e, double zlp, double zup, double zlv,
-                          double zuv, double &Hpp, double &Hvv, double &Hee, double &Hcc, double &gp,
-                          double &gv, double &ge, double &gc) const {
-    const double islp = frcp1(psi - yl), isup = frcp1(yu - psi), islv = frcp1(v - vl), isuv = frcp1(vu - v);
-    const double mub = lsm ? 0.0 : mu;
-    Hpp = lsm ? 1.0 : zlp * islp + zup * isup;
-    Hvv = lsm ? 1.0 : df * 2.0 * wv + zlv * islv + zuv * isuv;
-    Hee = lsm ? 1.0 : df * 2.0 * we;
-    Hcc = lsm ? 1.0 : df * 2.0 * wc;
+  MPC_HD void state_terms(R psi, R v, R c, R e, R zlp, R zup, R zlv,
+                          R zuv, R &Hpp, R &Hvv, R &Hee, R &Hcc, R &gp,
+                          R &gv, R &ge, R &gc) const {
+    const R islp = frcp1(psi - yl), isup = frcp1(yu - psi), islv = frcp1(v - vl), isuv = frcp1(vu - v);
+    const R mub = lsm ? R(0.0) : mu;
+    Hpp = lsm ? R(1.0) : zlp * islp + zup * isup;
+    Hvv = lsm ? R(1.0) : df * R(2.0) * wv + zlv * islv + zuv * isuv;
+    Hee = lsm ? R(1.0) : df * R(2.0) * we;
+    Hcc = lsm ? R(1.0) : df * R(2.0) * wc;
     gp = mub * (isup - islp);
-    gv = df * 2.0 * wv * (v - vref) + mub * (isuv - islv);
-    ge = df * 2.0 * we * e;
-    gc = df * 2.0 * wc * c;
+    gv = df * R(2.0) * wv * (v - vref) + mub * (isuv - islv);
+    ge = df * R(2.0) * we * e;
+    gc = df * R(2.0) * wc * c;
   }
 
-  MPC_HD void load_state(int k, int I, double *s) const {   /* s_k; k = 0 is the fixed initial state */
+  MPC_HD void load_state(int k, int I, R *s) const {   /* s_k; k = 0 is the fixed initial state */
     if (k == 0) {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) s[i] = st[i];
@@ -529,11 +671,11 @@ struct Solver {
   /* Returns false when some R~_k is not positive definite (wrong        */
   /* inertia): the caller raises the regularisation dw and repeats.      */
   /* ------------------------------------------------------------------ */
-  MPC_HD bool backward(double dw) {
+  MPC_HD bool backward(R dw) {
     const int I = it(cur), J = it(1 - cur);         /* J: where the gains go */
     /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1; only the lower triangle of the symmetric
      * matrices is ever written or read (PM/MX pick it), so the other half never occupies registers */
-    double Pm[6][6], p[6], Pcc, pc;
+    R Pm[6][6], p[6], Pcc, pc;
 #define PM(i, j) Pm[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
 #define MX(i, j) Mx[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
     MPC_UNROLL
@@ -542,36 +684,36 @@ struct Solver {
       MPC_UNROLL
       for (int j = 0; j < 6; j++) Pm[i][j] = 0;
     }
-    const double rsc = lsm ? 0.0 : -1.0;             /* constraint right-hand side: -c, or 0 for the LS system */
-    const double hxy = (lsm ? 1.0 : 0.0) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
+    const R rsc = lsm ? R(0.0) : -R(1.0);             /* constraint right-hand side: -c, or 0 for the LS system */
+    const R hxy = (lsm ? R(1.0) : R(0.0)) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
     /* Staging: record j of the iterate (the fields of stage j) sits in buffer (M-1-j)&1.  Stage k needs
      * (u_k, lam_{k+1}, duals of u_k) from record k -- moved to registers one iteration earlier -- and
      * (s_k, delta_{k-1}, duals of s_k) from record k-1; record k-2 is requested meanwhile. */
     ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
     ws.template stage_wait<0>();
-    double sn[6];                                    /* s_{k+1} */
+    R sn[6];                                    /* s_{k+1} */
     MPC_UNROLL
     for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
     {
-      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(sn[2], sn[3], sn[4], sn[5], ws.sit(0, M - 1, I, F_ZL + 0), ws.sit(0, M - 1, I, F_ZU + 0),
                   ws.sit(0, M - 1, I, F_ZL + 1), ws.sit(0, M - 1, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       Pm[0][0] = hxy; Pm[1][1] = hxy; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
       Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
     }
     /* inputs of stage k that live in record k, carried in registers */
-    double delta = ws.sit(0, M - 1, I, F_U + 0), acc = ws.sit(0, M - 1, I, F_U + 1);
-    double lx = ws.sit(0, M - 1, I, F_LAM + 0), ly = ws.sit(0, M - 1, I, F_LAM + 1), lp = ws.sit(0, M - 1, I, F_LAM + 2);
-    double lc = ws.sit(0, M - 1, I, F_LAM + 4), le = ws.sit(0, M - 1, I, F_LAM + 5);
-    double zld = ws.sit(0, M - 1, I, F_ZL + 2), zud = ws.sit(0, M - 1, I, F_ZU + 2);
-    double zla = ws.sit(0, M - 1, I, F_ZL + 3), zua = ws.sit(0, M - 1, I, F_ZU + 3);
+    R delta = ws.sit(0, M - 1, I, F_U + 0), acc = ws.sit(0, M - 1, I, F_U + 1);
+    R lx = ws.sit(0, M - 1, I, F_LAM + 0), ly = ws.sit(0, M - 1, I, F_LAM + 1), lp = ws.sit(0, M - 1, I, F_LAM + 2);
+    R lc = ws.sit(0, M - 1, I, F_LAM + 4), le = ws.sit(0, M - 1, I, F_LAM + 5);
+    R zld = ws.sit(0, M - 1, I, F_ZL + 2), zud = ws.sit(0, M - 1, I, F_ZU + 2);
+    R zla = ws.sit(0, M - 1, I, F_ZL + 3), zua = ws.sit(0, M - 1, I, F_ZU + 3);
     if (M >= 2) ws.stage_fetch_it(1, M - 2, I);
     MPC_STAGE_LOOP
     for (int k = M - 1; k >= 0; --k) {
       /* ---- inputs of stage k ---- */
-      double sk[6];
-      double zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
+      R sk[6];
+      R zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
       const int bk = (M - k) & 1;                    /* buffer of record k-1 */
       if (k > 0) {
         if (k >= 2) {
@@ -589,24 +731,24 @@ struct Solver {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = st[i];
       }
-      const double v = sk[3];
-      Lin L;
+      const R v = sk[3];
+      LinR L;
       linearise(sk, delta, acc, sn, L);
-      const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
-      const double r0 = rsc * L.c[0], r1 = rsc * L.c[1], r2 = rsc * L.c[2], r3 = rsc * L.c[3], rc = rsc * L.c[4], r4 = rsc * L.c[5];
-      const double vdt = v * dt;
-      const double Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
-      const double Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
+      const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+      const R r0 = rsc * L.c[0], r1 = rsc * L.c[1], r2 = rsc * L.c[2], r3 = rsc * L.c[3], rc = rsc * L.c[4], r4 = rsc * L.c[5];
+      const R vdt = v * dt;
+      const R Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
+      const R Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
       /* t = p + P r (the d component of r is zero) */
-      double t[6];
+      R t[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++)
         t[i] = p[i] + PM(i, 0) * r0 + PM(i, 1) * r1 + PM(i, 2) * r2 + PM(i, 3) * r3 + PM(i, 4) * r4;
-      const double tc = pc + Pcc * rc;
+      const R tc = pc + Pcc * rc;
       /* G^T applied to a (6-vector, c-scalar): outputs for inputs x,y,psi,v,e,delta,a */
 #define MPC_GT(w, wcs, o)                                                         \
   do {                                                                            \
-    const double w24_ = (w)[2] + (w)[4];                                          \
+    const R w24_ = (w)[2] + (w)[4];                                          \
     (o)[0] = (w)[0] + Aex * (w)[4] + Acx * (wcs);                                 \
     (o)[1] = (w)[1] - (wcs);                                                      \
     (o)[2] = Axp * (w)[0] + Ayp * (w)[1] + w24_;                                  \
@@ -615,39 +757,42 @@ struct Solver {
     (o)[5] = Bp * w24_ + (w)[5];                                                  \
     (o)[6] = dt * (w)[3];                                                         \
   } while (0)
-      double qt[7];
+      R qt[7];
       MPC_GT(t, tc, qt);
       /* the stage's own control terms */
-      const double isld = frcp1(delta - dl), isud = frcp1(du - delta), isla = frcp1(acc - al), isua = frcp1(au - acc);
-      double ddl = 0, Hdd = 0;
-      if (k >= 1 && !lsm) { ddl = delta - delprev; Hdd = df * 2.0 * wdd; }   /* LS start: all delta are 0 */
-      const double mub = lsm ? 0.0 : mu;
-      const double gdel = df * 2.0 * wd * delta + Hdd * ddl + mub * (isud - isld);
-      const double gacc = mub * (isua - isla);
-      const double rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
+      const R isld = frcp1(delta - dl), isud = frcp1(du - delta), isla = frcp1(acc - al), isua = frcp1(au - acc);
+      R ddl = 0, Hdd = 0;
+      if (k >= 1 && !lsm) { ddl = delta - delprev; Hdd = df * R(2.0) * wdd; }   /* LS start: all delta are 0 */
+      const R mub = lsm ? R(0.0) : mu;
+      const R gdel = df * R(2.0) * wd * delta + Hdd * ddl + mub * (isud - isld);
+      const R gacc = mub * (isua - isla);
+      const R rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
       /* control Hessian diagonal: cost + barrier, or the identity of the LS system */
-      const double Sgd = lsm ? 1.0 : df * 2.0 * wd + zld * isld + zud * isud, Sga = lsm ? 1.0 : zla * isla + zua * isua;
-      double w5[6], w6[6];
+      const R Sgd = lsm ? R(1.0) : df * R(2.0) * wd + zld * isld + zud * isud, Sga = lsm ? R(1.0) : zla * isla + zua * isua;
+      R w5[6], w6[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++) { w5[i] = Bp * (PM(i, 2) + PM(i, 4)) + PM(i, 5); w6[i] = dt * PM(i, 3); }
       if (k == 0) {
         /* only the feed-forward of u_0 is needed (ds_0 = 0) */
-        double o5[7], o6[7];
-        MPC_GT(w5, 0.0, o5);
-        MPC_GT(w6, 0.0, o6);
-        const double Rdd = o5[5] + Sgd + dw;
-        const double Rda = o6[5];
-        const double Raa = o6[6] + Sga + dw;
-        const double det = Rdd * Raa - Rda * Rda;
-        if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-        const double idet = frcp1(det);
-        ws.store2(0, J, F_GF, -(Raa * rt_d - Rda * rt_a) * idet, -(-Rda * rt_d + Rdd * rt_a) * idet);
+        R o5[7], o6[7];
+        MPC_GT(w5, R(0.0), o5);
+        MPC_GT(w6, R(0.0), o6);
+        const R Rdd = o5[5] + Sgd + dw;
+        const R Rda = o6[5];
+        const R Raa = o6[6] + Sga + dw;
+        const R det = Rdd * Raa - Rda * Rda;
+        if (!(Rdd > R(0.0)) || !(det > R(0.0))) return false;
+        const R idet = frcp1(det);
+        static_assert(F_GF % F::G == 0, "kff starts a group");
+        R gf[F::G] = {};
+        gf[0] = -(Raa * rt_d - Rda * rt_a) * idet; gf[1] = -(-Rda * rt_d + Rdd * rt_a) * idet;
+        ws.template store_run<F_GF, F::G>(0, J, gf);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
-      double Mx[7][7];
+      R Mx[7][7];
       {
-        double w[6], o[7];
+        R w[6], o[7];
         MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = PM(i, 0) + Aex * PM(i, 4);
         MPC_GT(w, Pcc * Acx, o);
@@ -660,7 +805,7 @@ struct Solver {
         for (int i = 0; i < 7; i++) Mx[i][1] = o[i];
         MPC_UNROLL
         for (int i = 0; i < 6; i++) w[i] = Axp * PM(i, 0) + Ayp * PM(i, 1) + PM(i, 2) + PM(i, 4);
-        MPC_GT(w, 0.0, o);
+        MPC_GT(w, R(0.0), o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][2] = o[i];
         MPC_UNROLL
@@ -670,14 +815,14 @@ struct Solver {
         for (int i = 0; i < 7; i++) Mx[i][3] = o[i];
         {
           /* input e only feeds cte+: column = G^T (0, Pcc*Ace) */
-          const double wcs = Pcc * Ace;
-          Mx[0][4] = Acx * wcs; Mx[1][4] = -wcs; Mx[2][4] = 0.0; Mx[3][4] = Acv * wcs; Mx[4][4] = Ace * wcs;
-          Mx[5][4] = 0.0; Mx[6][4] = 0.0;
+          const R wcs = Pcc * Ace;
+          Mx[0][4] = Acx * wcs; Mx[1][4] = -wcs; Mx[2][4] = R(0.0); Mx[3][4] = Acv * wcs; Mx[4][4] = Ace * wcs;
+          Mx[5][4] = R(0.0); Mx[6][4] = R(0.0);
         }
-        MPC_GT(w5, 0.0, o);
+        MPC_GT(w5, R(0.0), o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][5] = o[i];
-        MPC_GT(w6, 0.0, o);
+        MPC_GT(w6, R(0.0), o);
         MPC_UNROLL
         for (int i = 0; i < 7; i++) Mx[i][6] = o[i];
       }
@@ -689,35 +834,37 @@ struct Solver {
       Mx[4][3] += -lc * dt * ce;
       Mx[5][3] += -(lp + le) * dtLf;
       /* control terms */
-      const double Rdd = Mx[5][5] + Hdd + Sgd + dw;
-      const double Rda = Mx[6][5];
-      const double Raa = Mx[6][6] + Sga + dw;
-      const double det = Rdd * Raa - Rda * Rda;
-      if (!(Rdd > 0.0) || !(det > 0.0)) return false;
-      const double idet = frcp1(det);
-      const double i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
+      const R Rdd = Mx[5][5] + Hdd + Sgd + dw;
+      const R Rda = Mx[6][5];
+      const R Raa = Mx[6][6] + Sga + dw;
+      const R det = Rdd * Raa - Rda * Rda;
+      if (!(Rdd > R(0.0)) || !(det > R(0.0))) return false;
+      const R idet = frcp1(det);
+      const R i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
       /* S~ (2 x 6 over x,y,psi,v,e,d) */
-      double Sd[6], Sa[6], Kd[6], Ka[6];
+      R Sd[6], Sa[6], Kd[6], Ka[6];
       MPC_UNROLL
       for (int j = 0; j < 5; j++) { Sd[j] = Mx[5][j]; Sa[j] = Mx[6][j]; }
-      Sd[5] = -Hdd; Sa[5] = 0.0;
+      Sd[5] = -Hdd; Sa[5] = R(0.0);
       MPC_UNROLL
       for (int j = 0; j < 6; j++) {
         Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
         Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
       }
-      const double kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
+      const R kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
+      R gn[GAIN_SZ] = {};
       MPC_UNROLL
-      for (int j = 0; j < 6; j += 2) { ws.store2(k, J, F_GK + j, Kd[j], Kd[j + 1]); ws.store2(k, J, F_GK + 6 + j, Ka[j], Ka[j + 1]); }
-      ws.store2(k, J, F_GF, kfd, kfa);
+      for (int j = 0; j < 6; j++) { gn[j] = Kd[j]; gn[6 + j] = Ka[j]; }
+      gn[GK_N] = kfd; gn[GK_N + 1] = kfa;
+      ws.template store_run<F_GK, GAIN_SZ>(k, J, gn);
       /* ---- value function of stage k ---- */
-      double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
       state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
         MPC_UNROLL
         for (int j = 0; j <= i; j++) {
-          double q = (i < 5) ? Mx[i][j] : ((j == 5) ? Hdd : 0.0);
+          R q = (i < 5) ? Mx[i][j] : ((j == 5) ? Hdd : R(0.0));
           q += Sd[i] * Kd[j] + Sa[i] * Ka[j];
           Pm[i][j] = q;
         }
@@ -748,12 +895,12 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   MPC_HD void forward() {
     const int I = it(cur), J = it(1 - cur);
-    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
-    double ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
-    double rmax = 0.0, rzmax = 0.0;                 /* largest step ratios: alpha = min(1, tau / ratio) */
-    const double rsc = lsm ? 0.0 : 1.0;
-    dphi = 0.0; dxinf = 0.0; xinf = 0.0;
-    double sk[6];
+    R d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
+    R ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
+    R rmax = R(0.0), rzmax = R(0.0);                 /* largest step ratios: alpha = min(1, tau / ratio) */
+    const R rsc = lsm ? R(0.0) : R(1.0);
+    dphi = R(0.0); dxinf = R(0.0); xinf = R(0.0);
+    R sk[6];
     load_state(0, I, sk);
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
@@ -768,58 +915,60 @@ struct Solver {
         if (k == 0) ws.template stage_wait<STG_ITF_OPS + STG_X_OPS>();
         else ws.template stage_wait<STG_ITF_OPS + STG_X_OPS + ST_FORWARD>();
       } else ws.template stage_wait<0>();
-      double sn[6];
+      R sn[6];
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sn[i] = ws.sit(bf, k, I, F_S + i);
-      const double v = sk[3];
-      const double delta = ws.sit(bf, k, I, F_U + 0), acc = ws.sit(bf, k, I, F_U + 1);
-      Lin L;
+      const R v = sk[3];
+      const R delta = ws.sit(bf, k, I, F_U + 0), acc = ws.sit(bf, k, I, F_U + 1);
+      LinR L;
       linearise(sk, delta, acc, sn, L);
-      double dd = ws.sg(bf, k, J, GK_N + 0), da = ws.sg(bf, k, J, GK_N + 1);
+      R dd = ws.sg(bf, k, J, GK_N + 0), da = ws.sg(bf, k, J, GK_N + 1);
       if (k > 0) {
         dd += ws.sg(bf, k, J, 0) * d0 + ws.sg(bf, k, J, 1) * d1 + ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3 +
               ws.sg(bf, k, J, 4) * d5 + ws.sg(bf, k, J, 5) * ddprev;
         da += ws.sg(bf, k, J, 6) * d0 + ws.sg(bf, k, J, 7) * d1 + ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3 +
               ws.sg(bf, k, J, 10) * d5 + ws.sg(bf, k, J, 11) * ddprev;
       }
-      const double vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
-      const double n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
-      const double n1 = d1 + vdt * L.cp * d2 + dt * L.sp * d3 - rsc * L.c[1];
-      const double n2 = d2 + Apv * d3 + Bp * dd - rsc * L.c[2];
-      const double n3 = d3 + dt * da - rsc * L.c[3];
-      const double n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
-      const double n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
-      ws.store2(k, 0, F_D + D_S + 0, n0, n1); ws.store2(k, 0, F_D + D_S + 2, n2, n3);
-      ws.store2(k, 0, F_D + D_S + 4, n4, n5); ws.store2(k, 0, F_D + D_U + 0, dd, da);
-      const double q2 = n2, q3 = n3, q4 = n4, q5 = n5, qd = dd, qa = da;
+      const R vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
+      const R n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
+      const R n1 = d1 + vdt * L.cp * d2 + dt * L.sp * d3 - rsc * L.c[1];
+      const R n2 = d2 + Apv * d3 + Bp * dd - rsc * L.c[2];
+      const R n3 = d3 + dt * da - rsc * L.c[3];
+      const R n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
+      const R n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
+      {
+        const R dn[D_N] = {n0, n1, n2, n3, n4, n5, dd, da};
+        ws.template store_run<F_D, D_N>(k, 0, dn);
+      }
+      const R q2 = n2, q3 = n3, q4 = n4, q5 = n5, qd = dd, qa = da;
       /* bounded variables of this stage: psi_{k+1}, v_{k+1}, delta_k, a_k */
-      const double xs[4] = {sn[2], sn[3], delta, acc};
-      const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
-      const double dx[4] = {q2, q3, qd, qa};
+      const R xs[4] = {sn[2], sn[3], delta, acc};
+      const R lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+      const R dx[4] = {q2, q3, qd, qa};
       MPC_UNROLL
       for (int b = 0; b < 4; b++) {
-        const double isl = frcp1(xs[b] - lo[b]), isu = frcp1(hi[b] - xs[b]);
-        const double zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
-        rmax = fmax(rmax, fmax(-dx[b] * isl, dx[b] * isu));
-        const double dzl = mu * isl - zl - zl * isl * dx[b];
-        const double dzu = mu * isu - zu + zu * isu * dx[b];
-        rzmax = fmax(rzmax, fmax(-dzl * frcp1(zl), -dzu * frcp1(zu)));
+        const R isl = frcp1(xs[b] - lo[b]), isu = frcp1(hi[b] - xs[b]);
+        const R zl = ws.sit(bf, k, I, F_ZL + b), zu = ws.sit(bf, k, I, F_ZU + b);
+        rmax = mpc_max(rmax, mpc_max(-dx[b] * isl, dx[b] * isu));
+        const R dzl = mu * isl - zl - zl * isl * dx[b];
+        const R dzu = mu * isu - zu + zu * isu * dx[b];
+        rzmax = mpc_max(rzmax, mpc_max(-dzl * frcp1(zl), -dzu * frcp1(zu)));
         dphi += mu * (isu - isl) * dx[b];
       }
       /* objective part of the directional derivative */
-      double g = 2.0 * wc * sn[4] * q4 + 2.0 * we * sn[5] * q5 + 2.0 * wv * (sn[3] - vref) * q3 + 2.0 * wd * delta * qd;
-      if (k > 0) g += 2.0 * wdd * (delta - delprev) * (qd - ddprev);
+      R g = R(2.0) * wc * sn[4] * q4 + R(2.0) * we * sn[5] * q5 + R(2.0) * wv * (sn[3] - vref) * q3 + R(2.0) * wd * delta * qd;
+      if (k > 0) g += R(2.0) * wdd * (delta - delprev) * (qd - ddprev);
       dphi += df * g;
-      dxinf = fmax(dxinf, fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
-                               fmax(fmax(fabs(n4), fabs(n5)), fmax(fabs(dd), fabs(da)))));
-      xinf = fmax(xinf, fmax(fmax(fabs(sn[0]), fabs(sn[1])), fmax(fabs(sn[3]), fabs(sn[4]))));
+      dxinf = mpc_max(dxinf, mpc_max(mpc_max(mpc_max(mpc_abs(n0), mpc_abs(n1)), mpc_max(mpc_abs(n2), mpc_abs(n3))),
+                               mpc_max(mpc_max(mpc_abs(n4), mpc_abs(n5)), mpc_max(mpc_abs(dd), mpc_abs(da)))));
+      xinf = mpc_max(xinf, mpc_max(mpc_max(mpc_abs(sn[0]), mpc_abs(sn[1])), mpc_max(mpc_abs(sn[3]), mpc_abs(sn[4]))));
       d0 = n0; d1 = n1; d2 = n2; d3 = n3; d5 = n5; ddprev = dd; delprev = delta;
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sk[i] = sn[i];
     }
     /* fraction to the boundary, W&B eq. (15): alpha = min(1, tau / max ratio) */
-    amax = (rmax > tau) ? tau / rmax : 1.0;
-    az = (rzmax > tau) ? tau / rzmax : 1.0;
+    amax = (rmax > tau) ? tau / rmax : R(1.0);
+    az = (rzmax > tau) ? tau / rzmax : R(1.0);
   }
 
   /* ------------------------------------------------------------------ */
@@ -836,21 +985,21 @@ struct Solver {
   /* point as it stands (start point).  lmax returns max |dlam|.          */
   /* Step k (M..0) works on record k-1 = (s_k, u_{k-1}, lam_k, duals) and */
   /* on transition k = (s_k, u_k) -> s_{k+1} whose other inputs are       */
-  /* carried in registers from step k+1.                                  */
+  /* carried in registers from step k+1.                                 */
   /* ------------------------------------------------------------------ */
-  MPC_HD Eval costate_trial(double dw, double alpha, double alpha_l, double alpha_z, bool with_costate, double &lmax) {
+  MPC_HD EvalR costate_trial(R dw, R alpha, R alpha_l, R alpha_z, bool with_costate, R &lmax) {
     const int I = it(cur), J = it(1 - cur);
-    const double hxy = (lsm ? 1.0 : 0.0) + dw;
-    Eval R;
-    R.theta = 0; R.cinf = 0; R.f = 0; R.L = 0; R.dinf = 0; R.cmin = 1e300; R.cmax = 0; R.lsum = 0; R.zsum = 0; R.du0 = 0; R.ok = true;
-    lmax = 0.0;
-    const double ksm = IpmConst::kappa_sigma * mu, ksi = mu * (1.0 / IpmConst::kappa_sigma);
+    const R hxy = (lsm ? R(1.0) : R(0.0)) + dw;
+    EvalR Ev;
+    Ev.theta = 0; Ev.cinf = 0; Ev.f = 0; Ev.L = 0; Ev.dinf = 0; Ev.cmin = IC::huge; Ev.cmax = 0; Ev.lsum = 0; Ev.zsum = 0; Ev.du0 = 0; Ev.ok = true;
+    lmax = R(0.0);
+    const R ksm = IC::kappa_sigma * mu, ksi = mu * (R(1.0) / IC::kappa_sigma);
     /* carried from step k+1 -- current iterate: s_{k+1}, u_k, lam_{k+1}, d(delta_k), lam+_{k+1} */
-    double sn_o[6] = {0, 0, 0, 0, 0, 0}, del_o = 0, acc_o = 0, lx = 0, ly = 0, lp = 0, lc = 0, le = 0, ddk = 0;
-    double L0 = 0, L1 = 0, L2 = 0, L3 = 0, L4 = 0, L5 = 0;
+    R sn_o[6] = {0, 0, 0, 0, 0, 0}, del_o = 0, acc_o = 0, lx = 0, ly = 0, lp = 0, lc = 0, le = 0, ddk = 0;
+    R L0 = 0, L1 = 0, L2 = 0, L3 = 0, L4 = 0, L5 = 0;
     /* -- trial point: s_{k+1}, lam_{k+1}, u_k, duals of u_k, delta_{k+1} */
-    double sn_t[6] = {0, 0, 0, 0, 0, 0}, ln_t[6] = {0, 0, 0, 0, 0, 0}, del_t = 0, acc_t = 0, del_nx = 0;
-    double zdl_t = 0, zdu_t = 0, zal_t = 0, zau_t = 0;
+    R sn_t[6] = {0, 0, 0, 0, 0, 0}, ln_t[6] = {0, 0, 0, 0, 0, 0}, del_t = 0, acc_t = 0, del_nx = 0;
+    R zdl_t = 0, zdu_t = 0, zal_t = 0, zau_t = 0;
     /* staging: record j (iterate + direction of stage j) in buffer (M-1-j)&1 */
     ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
@@ -858,10 +1007,10 @@ struct Solver {
     MPC_STAGE_LOOP
     for (int k = M; k >= 0; --k) {
       const int bk = (M - k) & 1;                    /* buffer of record k-1 */
-      double s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
-      double zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0;     /* trial duals of psi_k, v_k: zl_psi, zu_psi, zl_v, zu_v */
-      double n_del_o = 0, n_acc_o = 0, n_ddk = 0, lo0 = 0, lo1 = 0, lo2 = 0, lo4 = 0, lo5 = 0;
-      double n_del_t = 0, n_acc_t = 0, n_zdl = 0, n_zdu = 0, n_zal = 0, n_zau = 0;
+      R s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
+      R zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0;     /* trial duals of psi_k, v_k: zl_psi, zu_psi, zl_v, zu_v */
+      R n_del_o = 0, n_acc_o = 0, n_ddk = 0, lo0 = 0, lo1 = 0, lo2 = 0, lo4 = 0, lo5 = 0;
+      R n_del_t = 0, n_acc_t = 0, n_zdl = 0, n_zdu = 0, n_zal = 0, n_zau = 0;
       if (k >= 1) {
         if (k >= 2) {
           ws.stage_fetch_it(bk ^ 1, k - 2, I);
@@ -870,23 +1019,23 @@ struct Solver {
           else ws.template stage_wait<STG_IT_OPS + STG_D_OPS + ST_TRIAL>();
         } else ws.template stage_wait<0>();
         const int r = k - 1;
-        double ds[6];
+        R ds[6];
         MPC_UNROLL
         for (int i = 0; i < 6; i++) { s_o[i] = ws.sit(bk, r, I, F_S + i); ds[i] = ws.sx(bk, r, F_D, D_S + i); }
-        const double lo3 = ws.sit(bk, r, I, F_LAM + 3);
+        const R lo3 = ws.sit(bk, r, I, F_LAM + 3);
         lo0 = ws.sit(bk, r, I, F_LAM + 0); lo1 = ws.sit(bk, r, I, F_LAM + 1); lo2 = ws.sit(bk, r, I, F_LAM + 2);
         lo4 = ws.sit(bk, r, I, F_LAM + 4); lo5 = ws.sit(bk, r, I, F_LAM + 5);
         n_del_o = ws.sit(bk, r, I, F_U + 0); n_acc_o = ws.sit(bk, r, I, F_U + 1);
-        const double ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
+        const R ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
         n_ddk = ddel;
-        if (r == 0) R.du0 = fmax(fabs(ddel), fabs(dacc));   /* the outputs' part of the step (termination polish) */
+        if (r == 0) Ev.du0 = mpc_max(mpc_abs(ddel), mpc_abs(dacc));   /* the outputs' part of the step (termination polish) */
         /* ---- costate: lam+_k ---- */
-        double dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
+        R dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
         if (with_costate) {
-          double Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+          R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
           state_terms(s_o[2], s_o[3], s_o[4], s_o[5], ws.sit(bk, r, I, F_ZL + 0), ws.sit(bk, r, I, F_ZU + 0),
                       ws.sit(bk, r, I, F_ZL + 1), ws.sit(bk, r, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-          double n0, n1, n2, n3, n4, n5;
+          R n0, n1, n2, n3, n4, n5;
           if (k == M) {
             n0 = -(hxy * ds[0]);
             n1 = -(hxy * ds[1]);
@@ -895,15 +1044,15 @@ struct Solver {
             n4 = -(gc + (Hcc + dw) * ds[4]);
             n5 = -(ge + (Hee + dw) * ds[5]);
           } else {
-            const double v = s_o[3];
-            Lin L;
+            const R v = s_o[3];
+            LinR L;
             linearise(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
-            const double sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
-            const double vdt = v * dt, Apv = del_o * dtLf;
+            const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+            const R vdt = v * dt, Apv = del_o * dtLf;
             /* curvature of stage k */
-            const double Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
-            const double Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
-            const double L25 = L2 + L5;
+            const R Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
+            const R Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+            const R L25 = L2 + L5;
             n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * ds[0];
             n1 = L1 - L4 - hxy * ds[1];
             n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds[2] - Hpv * ds[3];
@@ -914,7 +1063,7 @@ struct Solver {
           }
           L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
           dl0 = L0 - lo0; dl1 = L1 - lo1; dl2 = L2 - lo2; dl3 = L3 - lo3; dl4 = L4 - lo4; dl5 = L5 - lo5;
-          lmax = fmax(lmax, fmax(fmax(fmax(fabs(dl0), fabs(dl1)), fmax(fabs(dl2), fabs(dl3))), fmax(fabs(dl4), fabs(dl5))));
+          lmax = mpc_max(lmax, mpc_max(mpc_max(mpc_max(mpc_abs(dl0), mpc_abs(dl1)), mpc_max(mpc_abs(dl2), mpc_abs(dl3))), mpc_max(mpc_abs(dl4), mpc_abs(dl5))));
         }
         /* ---- trial: record k-1 ---- */
         lam_t[0] = lo0 + alpha_l * dl0; lam_t[1] = lo1 + alpha_l * dl1; lam_t[2] = lo2 + alpha_l * dl2;
@@ -923,83 +1072,86 @@ struct Solver {
         for (int i = 0; i < 6; i++) s_t[i] = s_o[i] + alpha * ds[i];
         n_del_t = n_del_o + alpha * ddel;
         n_acc_t = n_acc_o + alpha * dacc;
+        R rec[IT_SZ] = {};                           /* the trial record, stored group by group below */
         MPC_UNROLL
         for (int i = 0; i < 6; i += 2) {
-          ws.store2(r, J, F_S + i, s_t[i], s_t[i + 1]);
-          ws.store2(r, J, F_LAM + i, lam_t[i], lam_t[i + 1]);
-          R.lsum += fabs(lam_t[i]) + fabs(lam_t[i + 1]);
+          rec[F_S + i] = s_t[i]; rec[F_S + i + 1] = s_t[i + 1];
+          rec[F_LAM + i] = lam_t[i]; rec[F_LAM + i + 1] = lam_t[i + 1];
+          Ev.lsum += mpc_abs(lam_t[i]) + mpc_abs(lam_t[i + 1]);
         }
-        ws.store2(r, J, F_U, n_del_t, n_acc_t);
+        rec[F_U] = n_del_t; rec[F_U + 1] = n_acc_t;
+        ws.template store_run<F_S, F_ZL - F_S>(r, J, rec + F_S);      /* s, u, lam (+ padding) */
         /* duals of psi_k, v_k, delta_{k-1}, a_{k-1} */
-        const double xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
-        const double xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
-        const double dxb[4] = {ds[2], ds[3], ddel, dacc};
-        const double lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
-        double zln[4], zun[4], prod = 1.0;
+        const R xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
+        const R xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
+        const R dxb[4] = {ds[2], ds[3], ddel, dacc};
+        const R lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+        R zln[4], zun[4], prod = R(1.0);
         MPC_UNROLL
         for (int b = 0; b < 4; b++) {
-          const double islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
-          const double zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
-          const double dzl = mu * islo - zl - zl * islo * dxb[b];
-          const double dzu = mu * isuo - zu + zu * isuo * dxb[b];
-          const double sl = xn[b] - lo[b], su = hi[b] - xn[b];
-          if (!(sl > 0.0) || !(su > 0.0)) R.ok = false;
-          const double isl = frcp1(sl), isu = frcp1(su);
-          double a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
+          const R islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
+          const R zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
+          const R dzl = mu * islo - zl - zl * islo * dxb[b];
+          const R dzu = mu * isuo - zu + zu * isuo * dxb[b];
+          const R sl = xn[b] - lo[b], su = hi[b] - xn[b];
+          if (!(sl > R(0.0)) || !(su > R(0.0))) Ev.ok = false;
+          const R isl = frcp1(sl), isu = frcp1(su);
+          R a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
           /* kappa_sigma safeguard, W&B eq. (16) */
-          a = fmax(fmin(a, ksm * isl), ksi * isl);
-          c = fmax(fmin(c, ksm * isu), ksi * isu);
+          a = mpc_max(mpc_min(a, ksm * isl), ksi * isl);
+          c = mpc_max(mpc_min(c, ksm * isu), ksi * isu);
           zln[b] = a; zun[b] = c;
-          R.zsum += a + c;
-          const double pl = sl * a, pu = su * c;
-          R.cmin = fmin(R.cmin, fmin(pl, pu)); R.cmax = fmax(R.cmax, fmax(pl, pu));
+          Ev.zsum += a + c;
+          const R pl = sl * a, pu = su * c;
+          Ev.cmin = mpc_min(Ev.cmin, mpc_min(pl, pu)); Ev.cmax = mpc_max(Ev.cmax, mpc_max(pl, pu));
           prod *= sl * su;
         }
-        ws.store2(r, J, F_ZL + 0, zln[0], zln[1]); ws.store2(r, J, F_ZL + 2, zln[2], zln[3]);
-        ws.store2(r, J, F_ZU + 0, zun[0], zun[1]); ws.store2(r, J, F_ZU + 2, zun[2], zun[3]);
-        R.L += flog(prod);
+        MPC_UNROLL
+        for (int b = 0; b < 4; b++) { rec[F_ZL + b] = zln[b]; rec[F_ZU + b] = zun[b]; }
+        ws.template store_run<F_ZL, 8>(r, J, rec + F_ZL);
+        Ev.L += flog(prod);
         zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
         n_zdl = zln[2]; n_zdu = zun[2]; n_zal = zln[3]; n_zau = zun[3];
         /* objective terms of (s_k, u_{k-1}) */
-        const double dv = s_t[3] - vref;
-        R.f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
+        const R dv = s_t[3] - vref;
+        Ev.f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
       }
       if (k < M) {
         /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
-        Lin L;
+        LinR L;
         linearise(s_t, del_t, acc_t, sn_t, L);
         MPC_UNROLL
-        for (int i = 0; i < 6; i++) { R.theta += fabs(L.c[i]); R.cinf = fmax(R.cinf, fabs(L.c[i])); }
-        const double ddl = (k >= 1) ? del_t - n_del_t : 0.0;          /* delta_k - delta_{k-1} */
-        const double ddn = (k + 1 < M) ? del_nx - del_t : 0.0;        /* delta_{k+1} - delta_k */
-        if (k >= 1) R.f += wdd * ddl * ddl;
-        const double v = s_t[3], vdt = v * dt, Apv = del_t * dtLf, Bp = v * dtLf;
-        const double l25 = ln_t[2] + ln_t[5];
+        for (int i = 0; i < 6; i++) { Ev.theta += mpc_abs(L.c[i]); Ev.cinf = mpc_max(Ev.cinf, mpc_abs(L.c[i])); }
+        const R ddl = (k >= 1) ? del_t - n_del_t : R(0.0);          /* delta_k - delta_{k-1} */
+        const R ddn = (k + 1 < M) ? del_nx - del_t : R(0.0);        /* delta_{k+1} - delta_k */
+        if (k >= 1) Ev.f += wdd * ddl * ddl;
+        const R v = s_t[3], vdt = v * dt, Apv = del_t * dtLf, Bp = v * dtLf;
+        const R l25 = ln_t[2] + ln_t[5];
         /* rows of u_k */
-        const double rd = df * (2.0 * wd * del_t + 2.0 * wdd * ddl - 2.0 * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
-        const double ra = -dt * ln_t[3] - zal_t + zau_t;
-        R.dinf = fmax(R.dinf, fmax(fabs(rd), fabs(ra)));
+        const R rd = df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
+        const R ra = -dt * ln_t[3] - zal_t + zau_t;
+        Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_abs(rd), mpc_abs(ra)));
         /* rows of s_k (k>=1) with A_k of the trial point */
         if (k >= 1) {
-          const double r0 = lam_t[0] - (ln_t[0] + L.fp * ln_t[4] - L.g1 * ln_t[5]);
-          const double r1 = lam_t[1] - (ln_t[1] - ln_t[4]);
-          const double r2 = lam_t[2] - (-vdt * L.sp * ln_t[0] + vdt * L.cp * ln_t[1] + l25) - zs0 + zs1;
-          const double r3 = df * 2.0 * wv * (s_t[3] - vref) + lam_t[3] -
+          const R r0 = lam_t[0] - (ln_t[0] + L.fp * ln_t[4] - L.g1 * ln_t[5]);
+          const R r1 = lam_t[1] - (ln_t[1] - ln_t[4]);
+          const R r2 = lam_t[2] - (-vdt * L.sp * ln_t[0] + vdt * L.cp * ln_t[1] + l25) - zs0 + zs1;
+          const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] -
                             (dt * L.cp * ln_t[0] + dt * L.sp * ln_t[1] + Apv * l25 + ln_t[3] + dt * L.se * ln_t[4]) - zs2 + zs3;
-          const double r4 = df * 2.0 * wc * s_t[4] + lam_t[4];
-          const double r5 = df * 2.0 * we * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
-          R.dinf = fmax(R.dinf, fmax(fmax(fabs(r0), fabs(r1)), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+          const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
+          const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
+          Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(r0), mpc_abs(r1)), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
         }
       } else {
         /* terminal state rows */
-        const double r2 = lam_t[2] - zs0 + zs1;
-        const double r3 = df * 2.0 * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
-        const double r4 = df * 2.0 * wc * s_t[4] + lam_t[4];
-        const double r5 = df * 2.0 * we * s_t[5] + lam_t[5];
-        R.dinf = fmax(R.dinf, fmax(fmax(fabs(lam_t[0]), fabs(lam_t[1])), fmax(fmax(fabs(r2), fabs(r3)), fmax(fabs(r4), fabs(r5)))));
+        const R r2 = lam_t[2] - zs0 + zs1;
+        const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
+        const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
+        const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5];
+        Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(lam_t[0]), mpc_abs(lam_t[1])), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
       }
       /* carry to step k-1 */
       MPC_UNROLL
@@ -1008,19 +1160,19 @@ struct Solver {
       del_t = n_del_t; acc_t = n_acc_t; zdl_t = n_zdl; zdu_t = n_zdu; zal_t = n_zal; zau_t = n_zau;
       del_o = n_del_o; acc_o = n_acc_o; ddk = n_ddk; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5;
     }
-    if (!(R.theta == R.theta) || !(R.f == R.f) || !(R.L == R.L) || !(R.dinf == R.dinf)) R.ok = false;
-    return R;
+    if (!(Ev.theta == Ev.theta) || !(Ev.f == Ev.f) || !(Ev.L == Ev.L) || !(Ev.dinf == Ev.dinf)) Ev.ok = false;
+    return Ev;
   }
 
-  MPC_HD double kkt_error(const Eval &e, double mu_) const {
-    const double m = 6.0 * M, nb = 8.0 * M;
-    const double sd = fmax(IpmConst::s_max, (e.lsum + e.zsum) / (m + nb)) / IpmConst::s_max;
-    const double sc = fmax(IpmConst::s_max, e.zsum / nb) / IpmConst::s_max;
-    const double compl_ = fmax(fabs(e.cmax - mu_), fabs(e.cmin - mu_));
-    return fmax(fmax(e.dinf / sd, e.cinf), compl_ / sc);
+  MPC_HD R kkt_error(const EvalR &e, R mu_) const {
+    const R m = R(6.0) * M, nb = R(8.0) * M;
+    const R sd = mpc_max(IC::s_max, (e.lsum + e.zsum) / (m + nb)) / IC::s_max;
+    const R sc = mpc_max(IC::s_max, e.zsum / nb) / IC::s_max;
+    const R compl_ = mpc_max(mpc_abs(e.cmax - mu_), mpc_abs(e.cmin - mu_));
+    return mpc_max(mpc_max(e.dinf / sd, e.cinf), compl_ / sc);
   }
 
-  MPC_HD bool filter_rejects(double th, double ph) const {
+  MPC_HD bool filter_rejects(R th, R ph) const {
     bool r = false;
     r |= (nf > 0) && th >= fth0 && ph >= fph0;
     r |= (nf > 1) && th >= fth1 && ph >= fph1;
@@ -1028,12 +1180,12 @@ struct Solver {
     r |= (nf > 3) && th >= fth3 && ph >= fph3;
     return r;
   }
-  MPC_HD void filter_add(double th, double ph) {
+  MPC_HD void filter_add(R th, R ph) {
     int slot = nf;
     if (nf >= 4) {
       /* full: overwrite the entry with the largest theta (the least restrictive one) */
       slot = 0;
-      double worst = fth0;
+      R worst = fth0;
       if (fth1 > worst) { worst = fth1; slot = 1; }
       if (fth2 > worst) { worst = fth2; slot = 2; }
       if (fth3 > worst) { worst = fth3; slot = 3; }
@@ -1048,31 +1200,34 @@ struct Solver {
   MPC_HD void start_point() {
     for (int k = 0; k < M; ++k) {
       MPC_UNROLL
-      for (int i = 0; i < 6; i++) { ws.it(k, IT0, F_S + i) = 0.0; ws.it(k, IT0, F_LAM + i) = 0.0; }
+      for (int i = 0; i < 6; i++) { ws.it(k, IT0, F_S + i) = R(0.0); ws.it(k, IT0, F_LAM + i) = R(0.0); }
       ws.it(k, IT0, F_S + 2) = psi_start;
-      ws.it(k, IT0, F_U + 0) = 0.0; ws.it(k, IT0, F_U + 1) = 0.0;
+      ws.it(k, IT0, F_U + 0) = R(0.0); ws.it(k, IT0, F_U + 1) = R(0.0);
       MPC_UNROLL
-      for (int b = 0; b < 4; b++) { ws.it(k, IT0, F_ZL + b) = 1.0; ws.it(k, IT0, F_ZU + b) = 1.0; }
+      for (int b = 0; b < 4; b++) { ws.it(k, IT0, F_ZL + b) = R(1.0); ws.it(k, IT0, F_ZU + b) = R(1.0); }
       MPC_UNROLL
-      for (int i = 0; i < D_N; i++) ws.setD(k, i, 0.0);
+      for (int i = 0; i < D_N; i++) ws.setD(k, i, R(0.0));
     }
   }
 
   /* ------------------------------------------------------------------ */
   /* set-up: instance constants, start point (MPC.cpp:204-257)           */
   /* ------------------------------------------------------------------ */
-  MPC_HD int setup(const double *state6, const double *coef5, double yaw_lo, double yaw_hi, const double *w12,
+  MPC_HD int setup(const R *state6, const R *coef5, R yaw_lo, R yaw_hi, const R *w12,
                    bool write_start = true) {
     MPC_UNROLL
     for (int i = 0; i < 6; i++) st[i] = state6[i];
     MPC_UNROLL
     for (int i = 0; i < MPC_NCOEF; i++) coef[i] = coef5[i];
     yl = yaw_lo; yu = yaw_hi;
-    M = P.N - 1; dt = P.dt; iLf = 1.0 / P.Lf; dtLf = P.dt / P.Lf;
-    vl = -P.max_speed; vu = P.max_speed; dl = -P.max_steering; du = P.max_steering;
-    al = P.max_deceleration; au = P.max_acceleration;
-    fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = 0.0;
-    lsm = false; cur = 0; iters = 0; n_reg = 0; nf = 0; E.f = 0.0;
+    M = P.N - 1; dt = (R)P.dt; iLf = (R)(1.0 / P.Lf); dtLf = (R)(P.dt / P.Lf);
+    vl = (R)-P.max_speed; vu = (R)P.max_speed; dl = (R)-P.max_steering; du = (R)P.max_steering;
+    al = (R)P.max_deceleration; au = (R)P.max_acceleration;
+    fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = R(0.0);
+    lsm = false; cur = 0; iters = 0; n_reg = 0; nf = 0; E.f = R(0.0);
+    /* fp32: its own tolerance; the outputs cannot stop moving below the noise of an fp32 step */
+    tol = (R)(sizeof(R) == 8 ? P.tol : P.tol_f32);
+    out_tol = (R)(sizeof(R) == 8 ? P.out_step_tol : 0.6 * P.tol_f32);
     /* Branch outcomes at the start point xi = (state at index 0, zeros elsewhere):
      * for i >= 1 every variable is 0, so (MPC.cpp:72-112)
      *   |cte_i| < ctePanic  -> w[0] unless ctePanic <= 0
@@ -1082,30 +1237,30 @@ struct Solver {
     wc = (0.0 < P.cte_panic) ? w12[0] : w12[11];
     we = (0.0 > P.epsi_panic) ? w12[10] : w12[1];
     wv = w12[2]; wd = w12[3]; wdd = w12[4];
-    vref = speed_target(P, 0.0, P.max_speed);
+    vref = (R)speed_target(P, 0.0, P.max_speed);
     /* i = 0 terms: constants of the objective (their variables are fixed), MPC.cpp:71-92 */
-    const double wc0 = (fabs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
-    const double we0 = (fabs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
-    const double vref0 = speed_target(P, st[2], P.max_speed);
+    const R wc0 = ((double)mpc_abs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
+    const R we0 = ((double)mpc_abs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
+    const R vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
     cost0 = wc0 * st[4] * st[4] + we0 * st[5] * st[5] + wv * (st[3] - vref0) * (st[3] - vref0);
-    double g0 = fmax(fabs(2.0 * wc0 * st[4]), fabs(2.0 * we0 * st[5]));
-    double gv0 = 2.0 * wv * (st[3] - vref0);
-    if (st[3] < 0.0) { cost0 += w12[9] * st[3] * st[3]; gv0 += 2.0 * w12[9] * st[3]; }
-    g0 = fmax(g0, fabs(gv0));
+    R g0 = mpc_max(mpc_abs(R(2.0) * wc0 * st[4]), mpc_abs(R(2.0) * we0 * st[5]));
+    R gv0 = R(2.0) * wv * (st[3] - vref0);
+    if (st[3] < R(0.0)) { cost0 += w12[9] * st[3] * st[3]; gv0 += R(2.0) * w12[9] * st[3]; }
+    g0 = mpc_max(g0, mpc_abs(gv0));
     /* gradient-based objective scaling at the start point (IPOPT default) */
-    g0 = fmax(g0, fabs(2.0 * wv * vref));
-    df = (g0 > 100.0) ? fmax(100.0 / g0, 1e-8) : 1.0;
+    g0 = mpc_max(g0, mpc_abs(R(2.0) * wv * vref));
+    df = (g0 > R(100.0)) ? mpc_max(R(100.0) / g0, R(1e-8)) : R(1.0);
     /* start point: zeros (MPC.cpp:207-210), pushed into the interior like IPOPT does */
-    double psi0 = 0.0;
+    R psi0 = R(0.0);
     {
-      const double pl = fmin(IpmConst::kappa1 * fmax(1.0, fabs(yl)), IpmConst::kappa2 * (yu - yl));
-      const double pu = fmin(IpmConst::kappa1 * fmax(1.0, fabs(yu)), IpmConst::kappa2 * (yu - yl));
-      psi0 = fmin(fmax(psi0, yl + pl), yu - pu);
+      const R pl = mpc_min(IC::kappa1 * mpc_max(R(1.0), mpc_abs(yl)), IC::kappa2 * (yu - yl));
+      const R pu = mpc_min(IC::kappa1 * mpc_max(R(1.0), mpc_abs(yu)), IC::kappa2 * (yu - yl));
+      psi0 = mpc_min(mpc_max(psi0, yl + pl), yu - pu);
     }
     psi_start = psi0;
     if (write_start) start_point();   /* a parked instance that is being resumed brings its iterate along */
     /* the fixed initial state must satisfy its own bounds (MPC.cpp:229-239 vs :269-281) */
-    if (!(st[2] >= yl && st[2] <= yu) || !(fabs(st[3]) <= P.max_speed) || !(yl < yu)) return MPC_STATUS_INFEASIBLE;
+    if (!(st[2] >= yl && st[2] <= yu) || !(mpc_abs(st[3]) <= vu) || !(yl < yu)) return MPC_STATUS_INFEASIBLE;
     return MPC_STATUS_SUCCESS;
   }
 
@@ -1118,9 +1273,10 @@ struct Solver {
   /* state of the interior-point loop (see step()) */
   int phase, iter, n_polish;
   bool ls_start, tiny;
-  double out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
-  double alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
-  double theta_k, phi_k, pth, pdp, amin;   /* line-search state */
+  R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
+  R tol, out_tol;  /* "tol" of this precision (MpcParams.tol or tol_f32) and the polish's step tolerance */
+  R alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
+  R theta_k, phi_k, pth, pdp, amin;   /* line-search state */
 
   /* Solve from the start point that setup()/start_point() has written.
    * A line search that runs out of step length is where IPOPT would enter its feasibility-restoration phase.
@@ -1149,65 +1305,77 @@ struct Solver {
     a(0) = mu; a(1) = tau; a(2) = E.theta; a(3) = E.cinf; a(4) = E.f; a(5) = E.L; a(6) = E.dinf; a(7) = E.cmin; a(8) = E.cmax;
     a(9) = E.lsum; a(10) = E.zsum; a(11) = fth0; a(12) = fth1; a(13) = fth2; a(14) = fth3; a(15) = fph0; a(16) = fph1;
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
-    a(22) = (double)nf; a(23) = (double)iter; a(24) = (double)n_reg; a(25) = (double)cur; a(26) = E.ok ? 1.0 : 0.0;
-    a(27) = ls_start ? 1.0 : 0.0; a(28) = (double)attempt; a(29) = (double)it_total;
-    a(30) = out_step; a(31) = (double)n_polish; a(32) = 0.0; a(33) = 0.0; a(34) = 0.0; a(35) = 0.0;
+    a(22) = (R)nf; a(23) = (R)iter; a(24) = (R)n_reg; a(25) = (R)cur; a(26) = E.ok ? R(1.0) : R(0.0);
+    a(27) = ls_start ? R(1.0) : R(0.0); a(28) = (R)attempt; a(29) = (R)it_total;
+    a(30) = out_step; a(31) = (R)n_polish; a(32) = R(0.0); a(33) = R(0.0); a(34) = R(0.0); a(35) = R(0.0);
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
-    begin(a(27) != 0.0);
+    begin(a(27) != R(0.0));
     mu = a(0); tau = a(1); E.theta = a(2); E.cinf = a(3); E.f = a(4); E.L = a(5); E.dinf = a(6); E.cmin = a(7); E.cmax = a(8);
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
-    nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != 0.0;
+    nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != R(0.0);
     attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31);
     iters = iter; phase = PH_DIR;
   }
 
   MPC_HD void begin(bool ls) {
-    cur = 0; mu = IpmConst::mu_init; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
+    cur = 0; mu = IC::mu_init; tau = mpc_max(IC::tau_min, R(1.0) - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
     /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
-    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = 1e300;
-    alpha = alpha_l = alpha_z = dw_cur = 0.0;
-    theta_max = theta_min = dw_last = 0.0;
-    theta_k = phi_k = pth = pdp = amin = 0.0;
+    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = IC::huge;
+    alpha = alpha_l = alpha_z = dw_cur = R(0.0);
+    theta_max = theta_min = dw_last = R(0.0);
+    theta_k = phi_k = pth = pdp = amin = R(0.0);
+  }
+
+  /* No acceptable step.  fp64: IPOPT would enter its restoration phase (the caller's stand-in: one restart).  fp32: the
+   * usual reason is that the iterate sits on the noise floor of single precision (multipliers of ~1e3 carry 6e-5 of
+   * rounding into the dual residual, slacks of a few ulp cannot shrink), so a point whose optimality error is within
+   * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
+  MPC_HD int line_search_failed() const {
+    if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
+    return MPC_STATUS_LINESEARCH;
   }
 
   /* One pass of the interior-point loop, written as a small state machine so that each sweep has exactly ONE
    * call site (they are force-inlined; several call sites would multiply the code size), and so that the lanes of
    * a wave can be in different phases -- or, in the device kernel, on different instances:
    *   EVAL0     evaluate the start point
-   *   LS        least-squares multiplier start (W&B section 3.6, IPOPT default): one Riccati pass
+   *   LS        least-squares multiplier start (W&B section R(3.6), IPOPT default): one Riccati pass
    *             with identity Hessian; estimates above constr_mult_init_max = 1000 are discarded
    *   DIR       convergence test, barrier update, search direction, first trial of the line search
    *   BACKTRACK further trials of the same line search
    * Returns MPC_RUNNING, or the final status of this attempt. */
   MPC_HD int step() {
-    const double mu_floor = P.tol / 10.0;
+    /* floor of the barrier parameter: IPOPT's tol/10; the fp32 solver goes to tol/25 (2e-5 at the default tol_f32): what
+     * its answers lose against fp64 is mostly the barrier's pull on weakly active bounds (mu/z), not rounding, while
+     * slacks of active bounds (mu/z ~ 1e-6 on a ~ 4.47) must stay above a few ulp */
+    const R mu_floor = sizeof(R) == 8 ? tol / R(10.0) : tol / R(25.0);
     if (phase == PH_LS || phase == PH_DIR) {
       if (phase == PH_DIR) {
         iters = iter;
-        const double E0 = kkt_error(E, 0.0);
+        const R E0 = kkt_error(E, R(0.0));
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
-        if (E0 <= P.tol) {
+        if (E0 <= tol) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
            * that the point returned is the central-path point itself and not whichever iterate crossed tol first
-           * (an interior a_0 still moves by ~1e-4 per step there).  At most kMaxPolish extra iterations. */
-          if (!P.polish || n_polish >= kMaxPolish || iter >= P.max_iter || (mu <= mu_floor && out_step <= P.out_step_tol))
+           * (an interior a_0 still moves by ~R(1e-4) per step there).  At most kMaxPolish extra iterations. */
+          if (!P.polish || n_polish >= kMaxPolish || iter >= P.max_iter || (mu <= mu_floor && out_step <= out_tol))
             return MPC_STATUS_SUCCESS;
           ++n_polish;
-          if (mu > mu_floor) { mu = mu_floor; tau = fmax(IpmConst::tau_min, 1.0 - mu); nf = 0; }
+          if (mu > mu_floor) { mu = mu_floor; tau = mpc_max(IC::tau_min, R(1.0) - mu); nf = 0; }
         }
         if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
         /* barrier update, W&B eq. (7) */
-        while (kkt_error(E, mu) <= IpmConst::kappa_eps * mu && mu > mu_floor) {
-          mu = fmax(mu_floor, fmin(IpmConst::kappa_mu * mu, mu * sqrt(mu)));
+        while (kkt_error(E, mu) <= IC::kappa_eps * mu && mu > mu_floor) {
+          mu = mpc_max(mu_floor, mpc_min(IC::kappa_mu * mu, mu * mpc_sqrt(mu)));
           /* with the termination polish the solve ends at the floor anyway: a value within 3x of it (IPOPT's schedule
-           * lands on 2.4e-9 before 1e-9) goes there directly, which saves most instances one iteration */
-          if (P.polish && mu < 3.0 * mu_floor) mu = mu_floor;
-          tau = fmax(IpmConst::tau_min, 1.0 - mu);
+           * lands on R(2.4e-9) before R(1e-9)) goes there directly, which saves most instances one iteration */
+          if (P.polish && mu < R(3.0) * mu_floor) mu = mu_floor;
+          tau = mpc_max(IC::tau_min, R(1.0) - mu);
           nf = 0;
         }
 #if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
@@ -1217,50 +1385,50 @@ struct Solver {
       }
       lsm = (phase == PH_LS);
       /* search direction with inertia correction, W&B section 3.1 */
-      double dw = 0.0;
+      R dw = R(0.0);
       int tries = 0;
       bool okb = true;
       while (!backward(dw)) {
         if (lsm) { okb = false; break; }
-        if (dw == 0.0) dw = (dw_last == 0.0) ? IpmConst::dw_0 : fmax(IpmConst::dw_min, IpmConst::kw_minus * dw_last);
-        else dw *= (dw_last == 0.0) ? IpmConst::kw_plus_bar : IpmConst::kw_plus;
-        if (dw > IpmConst::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
+        if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
+        else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
+        if (dw > IC::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
       }
       if (okb) forward();
       dw_cur = dw;
       if (phase == PH_LS) {
         if (!okb) { lsm = false; ls_start = false; phase = PH_EVAL0; return MPC_RUNNING; }
-        alpha = 0.0; alpha_l = 1.0; alpha_z = 0.0;      /* lam <- lam_LS; primal point and bound duals unchanged */
+        alpha = R(0.0); alpha_l = R(1.0); alpha_z = R(0.0);      /* lam <- lam_LS; primal point and bound duals unchanged */
       } else {
-        if (dw > 0.0) { dw_last = dw; n_reg++; }
+        if (dw > R(0.0)) { dw_last = dw; n_reg++; }
         /* filter line search, W&B algorithm A */
         theta_k = E.theta; phi_k = df * E.f - mu * E.L;
-        pth = hpow(theta_k, IpmConst::s_theta);                       /* theta^s_theta */
-        pdp = (dphi < 0.0) ? hpow(-dphi, IpmConst::s_phi) : 0.0;      /* (-dphi)^s_phi */
-        if (dphi < 0.0) {
-          const double t3 = (theta_k <= theta_min) ? IpmConst::delta_sw * pth / pdp : IpmConst::gamma_theta;
-          amin = IpmConst::gamma_alpha * fmin(fmin(IpmConst::gamma_theta, IpmConst::gamma_phi * theta_k / (-dphi)), t3);
-        } else amin = IpmConst::gamma_alpha * IpmConst::gamma_theta;
-        tiny = dxinf <= 10.0 * IpmConst::eps * fmax(1.0, xinf);
+        pth = hpow(theta_k, IC::s_theta);                       /* theta^s_theta */
+        pdp = (dphi < R(0.0)) ? hpow(-dphi, IC::s_phi) : R(0.0);      /* (-dphi)^s_phi */
+        if (dphi < R(0.0)) {
+          const R t3 = (theta_k <= theta_min) ? IC::delta_sw * pth / pdp : IC::gamma_theta;
+          amin = IC::gamma_alpha * mpc_min(mpc_min(IC::gamma_theta, IC::gamma_phi * theta_k / (-dphi)), t3);
+        } else amin = IC::gamma_alpha * IC::gamma_theta;
+        tiny = dxinf <= R(10.0) * IC::eps * mpc_max(R(1.0), xinf);
         alpha = amax; alpha_l = amax; alpha_z = az;
       }
     }
-    double lmax;
-    const Eval T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
+    R lmax;
+    const EvalR T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
     if (phase == PH_EVAL0) {
       E = T; cur = 1;
       if (!E.ok) return MPC_STATUS_NUMERIC;
-      theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
+      theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta);
       phase = ls_start ? PH_LS : PH_DIR;
       return MPC_RUNNING;
     }
     if (phase == PH_LS) {
       lsm = false; ls_start = false;
       /* estimates above constr_mult_init_max = 1000 are discarded: the start point is then evaluated as it is */
-      if (lmax <= 1000.0) {
+      if (lmax <= R(1000.0)) {
         E = T; cur = 1 - cur;
         if (!E.ok) return MPC_STATUS_NUMERIC;
-        theta_max = 1e4 * fmax(1.0, E.theta); theta_min = 1e-4 * fmax(1.0, E.theta);
+        theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta);
         phase = PH_DIR;
       } else phase = PH_EVAL0;
       return MPC_RUNNING;
@@ -1269,22 +1437,25 @@ struct Solver {
     bool accepted = false, ftype = false;
     if (tiny) { accepted = T.ok; ftype = true; }
     else if (T.ok) {
-      const double phi_t = df * T.f - mu * T.L;
-      const double eps_phi = 10.0 * IpmConst::eps * fabs(phi_k);
+      const R phi_t = df * T.f - mu * T.L;
+      const R eps_phi = R(10.0) * IC::eps * mpc_abs(phi_k);
       if (T.theta < theta_max && !filter_rejects(T.theta, phi_t)) {
-        const bool sw = dphi < 0.0 && alpha * pdp > IpmConst::delta_sw * pth;
-        const bool armijo = phi_t - phi_k - eps_phi <= IpmConst::eta_phi * alpha * dphi;
+        const bool sw = dphi < R(0.0) && alpha * pdp > IC::delta_sw * pth;
+        const bool armijo = phi_t - phi_k - eps_phi <= IC::eta_phi * alpha * dphi;
         if (theta_k <= theta_min && sw) {
           if (armijo) accepted = true;
-        } else if (T.theta <= (1.0 - IpmConst::gamma_theta) * theta_k ||
-                   phi_t - phi_k - eps_phi <= -IpmConst::gamma_phi * theta_k) {
+        } else if (T.theta <= (R(1.0) - IC::gamma_theta) * theta_k ||
+                   phi_t - phi_k - eps_phi <= -IC::gamma_phi * theta_k) {
           accepted = true;
         }
         ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
       }
     }
+    if (accepted && sizeof(R) == 4 && n_polish > 0 && !(kkt_error(T, R(0.0)) <= R(10.0) * tol))
+      return MPC_STATUS_SUCCESS;   /* fp32: a polish step that throws the point out of the acceptable band (a slack of a few
+                                    * ulp collapsing) is dropped; the converged iterate stays */
     if (accepted) {
-      if (!ftype) filter_add((1.0 - IpmConst::gamma_theta) * theta_k, phi_k - IpmConst::gamma_phi * theta_k);
+      if (!ftype) filter_add((R(1.0) - IC::gamma_theta) * theta_k, phi_k - IC::gamma_phi * theta_k);
       cur = 1 - cur;
       E = T;
       out_step = alpha * T.du0;
@@ -1292,9 +1463,9 @@ struct Solver {
       phase = PH_DIR;
       return MPC_RUNNING;
     }
-    if (tiny) return MPC_STATUS_LINESEARCH;
-    alpha *= 0.5; alpha_l = alpha;
-    if (alpha < amin) return MPC_STATUS_LINESEARCH;
+    if (tiny) return line_search_failed();
+    alpha *= R(0.5); alpha_l = alpha;
+    if (alpha < amin) return line_search_failed();
     phase = PH_BACKTRACK;
     return MPC_RUNNING;
   }
@@ -1318,15 +1489,15 @@ struct Solver {
 
 /* One instance, end to end (used by the test-only host build; the device kernel
  * drives Solver directly so that outputs go straight to their HBM arrays). */
-template <class WS>
-MPC_HD int solve_instance(const MpcParams &P, WS ws, const double *state6, const double *coef5, double yaw_lo,
-                          double yaw_hi, const double *w12, double *out9, double *traj2N, int *iters_out) {
-  Solver<WS> S(P, ws);
+template <class WS, class R>
+MPC_HD int solve_instance(const MpcParams &P, WS ws, const R *state6, const R *coef5, R yaw_lo,
+                          R yaw_hi, const R *w12, R *out9, R *traj2N, int *iters_out) {
+  Solver<WS, R> S(P, ws);
   int status = S.setup(state6, coef5, yaw_lo, yaw_hi, w12);
   if (status == MPC_STATUS_SUCCESS) status = S.solve();
-  double *o = out9;
-  double *t = traj2N;
-  S.unpack([o](int i) -> double & { return o[i]; }, [t](int i) -> double & { return t[i]; }, traj2N != nullptr);
+  R *o = out9;
+  R *t = traj2N;
+  S.unpack([o](int i) -> R & { return o[i]; }, [t](int i) -> R & { return t[i]; }, traj2N != nullptr);
   if (iters_out) *iters_out = S.iters;
   return status;
 }

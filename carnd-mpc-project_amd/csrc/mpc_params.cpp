@@ -98,7 +98,7 @@ extern "C" int mpc_params_default(MpcParams *p) {
   p->max_iter = 200;
   p->tol = 1e-8;
   p->out_step_tol = 3e-7;
-  p->tol_f32 = 1e-4;
+  p->tol_f32 = 5e-4;
   p->polish = 1;
   return MPC_OK;
 }

@@ -31,6 +31,26 @@ thread_local std::string g_last_error;
     }                                                                                    \
   } while (0)
 
+/* Every entry point works on the handle's device and leaves the caller's current device as it found it. */
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+#define MPC_ON_DEVICE(h)                                                                 \
+  DeviceGuard guard_((h)->device);                                                       \
+  if (guard_.err != hipSuccess) {                                                        \
+    g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);        \
+    return MPC_ERR_HIP;                                                                  \
+  }
+
 constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchronise */
 constexpr int64_t kLdsPerCu = 160 * 1024;
 
@@ -40,7 +60,7 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
  * interleaved in pairs per lane (see mpc_core.h).  STAGING: every sweep double-buffers the next
  * stage's record into this workgroup's LDS with LDS-DMA (global_load_lds) while it computes.
  */
-constexpr size_t kStagingLdsBytes = 2u * mpc::STG_SLOT_PAIRS * 64u * 16u;   /* 36 KB per wave */
+template <class R> constexpr size_t staging_lds_bytes() { return 2u * mpc::Fields<R>::STG_SLOT * 64u * 16u; }   /* 36 KB per wave (fp64), 20 KB (fp32) */
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MPC_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)   /* over the active lanes of the wave */
@@ -69,25 +89,28 @@ struct MpcTwoPhase {
   int32_t *list_src;       /* parked: wave * 64 + lane of the tile column that holds its iterate */
   double *park;            /* [PARK_N][ld_park] solver scalars, column = position in the list */
   int64_t ld_park;
-  const double *src_ws;    /* phase B: workspace of phase A */
+  const void *src_ws;      /* phase B: workspace of phase A */
   int32_t pass_cut;        /* phase A: park after this many passes (0 = never) */
   int32_t resume;          /* 1 = phase B */
 };
 
-template <bool STAGING>
-__global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
-    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const double *__restrict__ state,
-    const double *__restrict__ coeffs, const double *__restrict__ yaw_lo, const double *__restrict__ yaw_hi,
-    const double *__restrict__ weights, double *__restrict__ out, double *__restrict__ traj,
-    int32_t *__restrict__ status, int32_t *__restrict__ iters, double *__restrict__ wsbase,
-    const int64_t tile_doubles, const MpcTwoPhase T) {
+/* OCC = waves per SIMD the register allocation is held to: the fp64 solver needs ~380 registers (1); the fp32 solver
+ * fits 256 with a few spilled values (2), or runs unconstrained (1) */
+template <bool STAGING, class R, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
+    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
+    const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
+    const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters, R *__restrict__ wsbase,
+    const int64_t tile_reals, const MpcTwoPhase T) {
   extern __shared__ double smem[];
-  using WS = mpc::TiledWorkspace<STAGING>;
-  using SV = mpc::Solver<WS>;
+  using WS = mpc::TiledWorkspace<STAGING, R>;
+  using SV = mpc::Solver<WS, R>;
+  using FL = mpc::Fields<R>;
   WS ws;
-  ws.tile = (mpc::gdouble *)(wsbase + (int64_t)blockIdx.x * tile_doubles);
+  ws.tile = (typename WS::greal *)(wsbase + (int64_t)blockIdx.x * tile_reals);
   ws.lane = threadIdx.x;
-  ws.lbuf = (mpc::ldouble *)smem;
+  ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
   int64_t i = 0;
   bool have = false, more = true;      /* holds an instance / may still get one */
@@ -99,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
       more = pos < n_work;
       if (more) {
         i = T.resume ? (int64_t)T.list_inst[pos] : pos;
-        double st[6], cf[MPC_NCOEF], w[MPC_NW];
+        R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
         for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
 #pragma unroll
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
           for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
         } else {
 #pragma unroll
-          for (int q = 0; q < MPC_NW; q++) w[q] = P.weights[q];
+          for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
         }
         const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
         if (T.resume) {
@@ -119,21 +142,23 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
           S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
           const int src = T.list_src[pos];
           WS wsrc = ws;
-          wsrc.tile = (mpc::gdouble *)(T.src_ws + (int64_t)(src >> 6) * tile_doubles);
+          wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
           wsrc.lane = src & 63;
-          const int I = S.cur ? mpc::IT1 : mpc::IT0;
+          const int I = S.cur ? FL::IT1 : FL::IT0;
           for (int k = 0; k < P.N - 1; ++k) {
+            R rec[FL::IT_SZ];
 #pragma unroll
-            for (int f = 0; f < mpc::IT_SZ; f += 2) ws.store2(k, I, f, wsrc.it(k, I, f), wsrc.it(k, I, f + 1));
+            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
+            ws.template store_run<0, FL::IT_SZ>(k, I, rec);
           }
           passes = 0; have = true;
         } else if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
         else {
           /* rejected at set-up (initial state outside its own bounds): report the start point, ask again */
-          double *o = out + i;
-          double *t = traj ? traj + i : nullptr;
+          R *o = out + i;
+          R *t = traj ? traj + i : nullptr;
           const int64_t l = ldo;
-          S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; }, traj != nullptr);
+          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
           status[i] = s0;
           if (iters) iters[i] = 0;
         }
@@ -150,10 +175,10 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
           S.start_point();
           S.begin(false);
         } else {
-          double *o = out + i;
-          double *t = traj ? traj + i : nullptr;
+          R *o = out + i;
+          R *t = traj ? traj + i : nullptr;
           const int64_t l = ldo;
-          S.unpack([o, l](int q) -> double & { return o[q * l]; }, [t, l](int q) -> double & { return t[q * l]; }, traj != nullptr);
+          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
           status[i] = r;
           if (iters) iters[i] = S.iters + it_total;
           have = false;
@@ -236,6 +261,38 @@ __global__ __launch_bounds__(256) void mpc_rollout_step_kernel(int64_t B, int64_
   if (iters) iters[i] = (first ? 0 : iters[i]) + it_step[i];
 }
 
+/* Statistics of a batch, accumulated into handle-owned memory right behind the solve (mpc_get_stats never touches
+ * the caller's arrays again): acc[0..4] = instances per status code, acc[5] = sum of iterations, acc[6] = max. */
+__global__ __launch_bounds__(256) void mpc_stats_kernel(int64_t B, const int32_t *__restrict__ status, const int32_t *__restrict__ iters,
+                                                        unsigned long long *__restrict__ acc) {
+  __shared__ unsigned int cnt[5];
+  __shared__ unsigned long long isum;
+  __shared__ int imax;
+  if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { isum = 0; imax = 0; }
+  __syncthreads();
+  unsigned int my[5] = {0, 0, 0, 0, 0};
+  unsigned long long ms = 0;
+  int mm = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t st = status[i];
+    const int c = (st >= 0 && st < 4) ? st : 4;
+#pragma unroll
+    for (int q = 0; q < 5; q++) my[q] += (c == q);
+    const int it = iters ? iters[i] : 0;
+    ms += (unsigned long long)it;
+    mm = it > mm ? it : mm;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; q++) if (my[q]) atomicAdd(&cnt[q], my[q]);
+  if (ms) atomicAdd(&isum, ms);
+  if (mm) atomicMax(&imax, mm);
+  __syncthreads();
+  if (threadIdx.x < 5 && cnt[threadIdx.x]) atomicAdd(&acc[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+  if (threadIdx.x == 5 && isum) atomicAdd(&acc[5], isum);
+  if (threadIdx.x == 6 && imax) atomicMax(&acc[6], (unsigned long long)imax);
+}
+
 __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -251,15 +308,20 @@ struct MpcHandle {
   MpcParams params;
   int device = 0;
   int64_t max_batch = 0;
-  int64_t ws_stride = 0;   /* doubles per wavefront tile of the workspace */
+  int64_t ws_stride = 0;   /* reals (double, or float for MPC_PRECISION_F32) per wavefront tile of the workspace */
   bool staging = true;
+  bool occ2 = true;        /* fp32: the two-waves-per-SIMD build of the kernel (MPC_F32_OCC=1 selects the unconstrained one) */
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
-  double *ws = nullptr;
+  void *ws = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  /* device staging for the host-pointer entry point and for statistics */
-  double *d_in = nullptr;     /* state[6] coeffs[5] ylo yhi weights[12] = 25 rows */
-  double *d_out = nullptr;    /* out[9] traj[2N] */
+  /* staging of the host-pointer entry point: ONE device block and its pinned host mirror, rows with a per-call
+   * leading dimension: in = state[6] coeffs[5] ylo yhi weights[12] (25 rows) | out = out[9] traj[2N] | one row holding
+   * status and iters (int32 each) -- so a call is one copy in, the launch, one copy out */
+  double *d_io = nullptr, *h_io = nullptr;
+  unsigned long long *d_stats = nullptr;   /* [8] statistics of the last batch (mpc_stats_kernel) */
+  hipEvent_t ev_stats = nullptr;
+  bool have_stats = false;
   double *d_run = nullptr;    /* run(): pre[15] rows */
   double *d_run9 = nullptr;   /* run(): solve()'s 9 rows, caller's leading dimension */
   int64_t run9_ld = 0;
@@ -268,11 +330,11 @@ struct MpcHandle {
   /* two-phase solve: second workspace, parked-instance list and scalars (allocated on first use) */
   int pass_cut = 0;           /* MpcParams.pass_cut, or MPC_PASS_CUT in the environment (0 = single launch) */
   int64_t two_phase_min = 8192;
-  double *ws2 = nullptr, *d_park = nullptr;
+  void *ws2 = nullptr;
+  double *d_park = nullptr;
   int32_t *d_list = nullptr;
   /* last call */
   int64_t last_B = 0;
-  const int32_t *last_status = nullptr, *last_iters = nullptr;
   bool timed = false;
 };
 
@@ -282,8 +344,11 @@ static int validate_params(const MpcParams *p) {
   if (p->N < 3 || p->N > MPC_MAX_N) { g_last_error = "N out of range"; return MPC_ERR_INVALID; }
   if (!(p->dt > 0) || !(p->Lf > 0) || !(p->max_speed > 0) || !(p->max_steering > 0)) { g_last_error = "bad dt/Lf/limits"; return MPC_ERR_INVALID; }
   if (p->n_steers < 0 || p->n_steers > MPC_MAX_TABLE || p->n_steer_speeds < 1 || p->n_steer_speeds > MPC_MAX_TABLE) { g_last_error = "bad steer tables"; return MPC_ERR_INVALID; }
+  if (p->n_yaw_changes < 0 || p->n_yaw_changes > MPC_MAX_TABLE || p->n_yaw_change_speeds < 0 || p->n_yaw_change_speeds > MPC_MAX_TABLE) { g_last_error = "bad yaw-change tables"; return MPC_ERR_INVALID; }
+  if (!(p->out_step_tol >= 0)) { g_last_error = "bad out_step_tol"; return MPC_ERR_INVALID; }
   if (p->branch_mode != MPC_BRANCH_FROZEN) { g_last_error = "branch_mode LIVE is not implemented on the device path"; return MPC_ERR_UNSUPPORTED; }
-  if (p->precision != MPC_PRECISION_F64) { g_last_error = "precision F32 is not implemented yet"; return MPC_ERR_UNSUPPORTED; }
+  if (p->precision != MPC_PRECISION_F64 && p->precision != MPC_PRECISION_F32) { g_last_error = "unknown precision"; return MPC_ERR_INVALID; }
+  if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
   return MPC_OK;
 }
@@ -299,7 +364,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_last_error = "no HIP device"; return MPC_ERR_NO_DEVICE; }
   if (device < 0) MPC_HIP_CHECK(hipGetDevice(&device));
   if (device >= ndev) { g_last_error = "device index out of range"; return MPC_ERR_NO_DEVICE; }
-  MPC_HIP_CHECK(hipSetDevice(device));
+  DeviceGuard guard_(device);   /* the caller's current device is restored on return */
+  MPC_HIP_CHECK(guard_.err);
   hipDeviceProp_t prop;
   MPC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
@@ -313,10 +379,15 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
    * MPC_STAGING=0 selects the variant with ordinary loads (for A/B measurements). */
   h->staging = true;
   if (const char *e = getenv("MPC_STAGING")) h->staging = atoi(e) != 0;
-  (void)hipFuncSetAttribute((const void *)mpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-  h->ws_stride = mpc::workspace_fields_per_instance(p->N, false) * 64;   /* doubles per wavefront tile */
+  const bool f32 = p->precision == MPC_PRECISION_F32;
+  if (const char *e = getenv("MPC_F32_OCC")) h->occ2 = atoi(e) != 1;
+  if (f32) {
+    MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+  } else MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+  h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
   h->io_stride = (max_batch + 63) / 64 * 64;
-  const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
+  const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -326,6 +397,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_counter, 4 * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   h->pass_cut = p->pass_cut > 0 ? p->pass_cut : 0;
   if (const char *e3 = getenv("MPC_PASS_CUT")) { h->pass_cut = atoi(e3); if (h->pass_cut < 0) h->pass_cut = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
@@ -337,18 +410,20 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
   int rc = validate_params(p);
   if (rc != MPC_OK) return rc;
-  if (p->N != h->params.N) { g_last_error = "N cannot change on a live handle (workspace is sized by N)"; return MPC_ERR_INVALID; }
+  if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
   h->params = *p;
   return MPC_OK;
 }
 
 extern "C" void mpc_destroy(MpcHandle *h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard_(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
-  if (h->d_in) (void)hipFree(h->d_in);
-  if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_io) (void)hipFree(h->d_io);
+  if (h->h_io) (void)hipHostFree(h->h_io);
+  if (h->d_stats) (void)hipFree(h->d_stats);
+  if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
   if (h->d_run) (void)hipFree(h->d_run);
   if (h->d_run9) (void)hipFree(h->d_run9);
   if (h->d_status) (void)hipFree(h->d_status);
@@ -364,16 +439,35 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   delete h;
 }
 
+/* statistics of (status, iters) into the handle's own counters, behind whatever wrote them on stream s */
+static int record_stats(MpcHandle *h, int64_t B, const int32_t *status, const int32_t *iters, hipStream_t s) {
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), s));
+  unsigned grid = (unsigned)((B + 256 * 8 - 1) / (256 * 8));
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(mpc_stats_kernel, dim3(grid), dim3(256), 0, s, B, status, iters, h->d_stats);
+  MPC_HIP_CHECK(hipGetLastError());
+  MPC_HIP_CHECK(hipEventRecord(h->ev_stats, s));
+  h->have_stats = true;
+  return MPC_OK;
+}
+
 /* the launch; ld = leading dimension of the inputs, ldo = of out/traj */
-static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const double *state, const double *coeffs,
-                        const double *yaw_lo, const double *yaw_hi, const double *weights, double *out, double *traj,
-                        int32_t *status, int32_t *iters, void *stream_) {
+template <class R>
+static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs,
+                        const R *yaw_lo, const R *yaw_hi, const R *weights, R *out, R *traj,
+                        int32_t *status, int32_t *iters, void *stream_, bool with_stats = true) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if ((h->params.precision == MPC_PRECISION_F32) != (sizeof(R) == 4)) {
+    g_last_error = "this handle was created with the other precision: fp64 handles take the double entry points, "
+                   "MPC_PRECISION_F32 handles mpc_solve_batch_device_f32";
+    return MPC_ERR_INVALID;
+  }
   if (B < 0 || ld < B || ldo < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
-  h->last_B = B; h->last_status = status; h->last_iters = iters ? iters : h->d_iters; h->timed = false;
+  h->last_B = B; h->timed = false; h->have_stats = false;
   if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  MPC_ON_DEVICE(h);   /* workspace, lazy allocations and a NULL stream all belong to the handle's device */
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
   /* waves: one lane per instance, or fewer waves whose lanes take several instances in turn (instances_per_lane) */
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
@@ -381,7 +475,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   if (waves < 1) waves = 1;
   const bool two = h->pass_cut > 0 && h->inst_per_lane == 1 && B >= h->two_phase_min;
   if (two && !h->ws2) {
-    const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(double);
+    const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(R);
     MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
     MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 36 * h->io_stride));
     MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 2 * h->io_stride));
@@ -392,26 +486,31 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   int32_t *it_out = iters ? iters : h->d_iters;
   MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  auto launch = [&](unsigned grid, double *wsp, const MpcTwoPhase &tp) {
-    if (h->staging)
-      hipLaunchKernelGGL(mpc_solve_kernel<true>, dim3(grid), dim3(kBlock), kStagingLdsBytes, s, h->params, B, ld, ldo, state, coeffs,
-                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, wsp, h->ws_stride, tp);
+  auto launch = [&](unsigned grid, void *wsp, const MpcTwoPhase &tp) {
+    constexpr int kOcc2 = sizeof(R) == 4 ? 2 : 1;
+    if (h->staging && h->occ2)
+      hipLaunchKernelGGL((mpc_solve_kernel<true, R, kOcc2>), dim3(grid), dim3(kBlock), staging_lds_bytes<R>(), s, h->params, B, ld, ldo, state, coeffs,
+                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, (R *)wsp, h->ws_stride, tp);
+    else if (h->staging)
+      hipLaunchKernelGGL((mpc_solve_kernel<true, R, 1>), dim3(grid), dim3(kBlock), staging_lds_bytes<R>(), s, h->params, B, ld, ldo, state, coeffs,
+                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, (R *)wsp, h->ws_stride, tp);
     else
-      hipLaunchKernelGGL(mpc_solve_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
-                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, wsp, h->ws_stride, tp);
+      hipLaunchKernelGGL((mpc_solve_kernel<false, R, 1>), dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
+                         yaw_lo, yaw_hi, weights, out, traj, status, it_out, (R *)wsp, h->ws_stride, tp);
   };
   launch((unsigned)waves, h->ws, T);
   if (two) {
     /* phase B: the parked instances, re-packed; its grid covers half the batch, and lanes take further work from the
      * list if more than that was parked */
     MPC_HIP_CHECK(hipGetLastError());
-    MpcTwoPhase R = T;
-    R.resume = 1; R.pass_cut = 0;
-    launch((unsigned)((waves + 1) / 2), h->ws2, R);
+    MpcTwoPhase T2 = T;
+    T2.resume = 1; T2.pass_cut = 0;
+    launch((unsigned)((waves + 1) / 2), h->ws2, T2);
   }
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
+  if (with_stats) return record_stats(h, B, status, it_out, s);
   return MPC_OK;
 }
 
@@ -419,7 +518,15 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
                                       const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                                       const double *weights, double *out, double *traj, int32_t *status,
                                       int32_t *iters, void *stream_) {
-  return launch_solve(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
+  return launch_solve<double>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
+}
+
+/* MPC_PRECISION_F32: the same solve with fp32 inputs, outputs and workspace (handle created with precision F32) */
+extern "C" int mpc_solve_batch_device_f32(MpcHandle *h, int64_t B, int64_t ld, const float *state,
+                                          const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                                          const float *weights, float *out, float *traj, int32_t *status,
+                                          int32_t *iters, void *stream_) {
+  return launch_solve<float>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
 }
 
 /* run() for a batch; `tel` selects the telemetry rows as input (with latency compensation) and `cmd` the reply */
@@ -431,7 +538,11 @@ static int run_impl(MpcHandle *h, int64_t B, int64_t ld, int npts, const double 
   if (npts < 3 || npts > mpc::RUN_MAX_PTS) { g_last_error = "npts must be 3..8"; return MPC_ERR_INVALID; }
   if (B == 0) { h->last_B = 0; return MPC_OK; }
   if (!pose || !ptsx || !ptsy || !(out8 || cmd) || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
-  MPC_HIP_CHECK(hipSetDevice(h->device));
+  /* the tables MPC::run() looks up (Vehicle.cpp:34-79) must exist, and the fit is built for orders 2..4
+   * (Config::maxFitOrder <= 5, as in every config-*.json; the reference would go on to higher orders) */
+  if (h->params.n_yaw_change_speeds < 1 || h->params.n_steer_speeds < 1) { g_last_error = "run(): empty speed tables (load a config-*.json)"; return MPC_ERR_INVALID; }
+  if (h->params.max_fit_order > 5) { g_last_error = "run(): max_fit_order > 5 is not built (fit orders 2..4)"; return MPC_ERR_UNSUPPORTED; }
+  MPC_ON_DEVICE(h);
   const int64_t S = h->io_stride;
   if (!h->d_run) MPC_HIP_CHECK(hipMalloc((void **)&h->d_run, sizeof(double) * 15 * S));
   if (!h->d_run9 || h->run9_ld < ld) {       /* solve()'s 9 rows, with the caller's leading dimension (traj shares it) */
@@ -446,7 +557,7 @@ static int run_impl(MpcHandle *h, int64_t B, int64_t ld, int npts, const double 
   if (tel) hipLaunchKernelGGL(mpc_run_pre_kernel<true>, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, extra, ptsx, ptsy, d_pre, S);
   else hipLaunchKernelGGL(mpc_run_pre_kernel<false>, dim3(grid), dim3(256), 0, s, h->params, B, ld, npts, pose, 0.0, ptsx, ptsy, d_pre, S);
   MPC_HIP_CHECK(hipGetLastError());
-  int rc = launch_solve(h, B, S, ld, d_pre, d_pre + 6 * S, d_pre + 11 * S, d_pre + 12 * S, nullptr, h->d_run9, traj, status, iters, stream_);
+  int rc = launch_solve<double>(h, B, S, ld, d_pre, d_pre + 6 * S, d_pre + 11 * S, d_pre + 12 * S, nullptr, h->d_run9, traj, status, iters, stream_);
   if (rc != MPC_OK) return rc;
   hipLaunchKernelGGL(mpc_run_post_kernel, dim3(grid), dim3(256), 0, s, h->params, B, d_pre, S, h->d_run9, ld, out8, cmd, ld);
   MPC_HIP_CHECK(hipGetLastError());
@@ -475,7 +586,7 @@ extern "C" int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int
   if (steps < 1) { g_last_error = "steps < 1"; return MPC_ERR_INVALID; }
   if (B == 0) { h->last_B = 0; return MPC_OK; }
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
-  MPC_HIP_CHECK(hipSetDevice(h->device));
+  MPC_ON_DEVICE(h);
   if (!hist && (!h->d_run9 || h->run9_ld < ld)) {
     if (h->d_run9) MPC_HIP_CHECK(hipFree(h->d_run9));
     h->d_run9 = nullptr;
@@ -487,17 +598,17 @@ extern "C" int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int
   const unsigned grid = (unsigned)((B + 255) / 256);
   for (int t = 0; t < steps; t++) {
     double *o9 = hist ? hist + (int64_t)t * 9 * ld : h->d_run9;
-    int rc = launch_solve(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, o9, nullptr, h->d_rstat, h->d_iters, stream_);
+    int rc = launch_solve<double>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, o9, nullptr, h->d_rstat, h->d_iters, stream_, false);
     if (rc != MPC_OK) return rc;
     hipLaunchKernelGGL(mpc_rollout_step_kernel, dim3(grid), dim3(256), 0, s, B, ld, t == 0, o9, state, h->d_rstat, h->d_iters, status, iters);
     MPC_HIP_CHECK(hipGetLastError());
   }
-  h->last_status = status; h->last_iters = iters ? iters : h->d_iters;
-  return MPC_OK;
+  return record_stats(h, B, status, iters, s);   /* worst status per instance, iterations summed over the steps */
 }
 
 extern "C" int mpc_synchronize(MpcHandle *h) {
   if (!h) return MPC_ERR_INVALID;
+  MPC_ON_DEVICE(h);
   MPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   return MPC_OK;
 }
@@ -508,30 +619,42 @@ extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const d
                                     int32_t *iters) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
   if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
-  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (B == 0) { h->last_B = 0; h->have_stats = false; return MPC_OK; }
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
-  MPC_HIP_CHECK(hipSetDevice(h->device));
+  MPC_ON_DEVICE(h);
   const int N = h->params.N;
   const int64_t S = h->io_stride;
-  if (!h->d_in) MPC_HIP_CHECK(hipMalloc((void **)&h->d_in, sizeof(double) * 25 * S));
-  if (!h->d_out) MPC_HIP_CHECK(hipMalloc((void **)&h->d_out, sizeof(double) * (9 + 2 * MPC_MAX_N) * S));
-  double *d_state = h->d_in, *d_coef = d_state + 6 * S, *d_ylo = d_coef + 5 * S, *d_yhi = d_ylo + S, *d_w = d_yhi + S;
-  double *d_o = h->d_out, *d_t = d_o + 9 * S;
+  constexpr int kInRows = 6 + MPC_NCOEF + 2 + MPC_NW;              /* 25 */
+  const int kOutRows = MPC_NOUT + 2 * N + 1;                       /* out, traj, one row of status|iters (N is fixed per handle) */
+  if (!h->d_io) {
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_io, sizeof(double) * (kInRows + kOutRows) * S));
+    MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_io, sizeof(double) * (kInRows + kOutRows) * S, hipHostMallocDefault));
+  }
+  /* rows packed with leading dimension L (B rounded up to 8: 64-byte rows), so each direction is ONE copy */
+  const int64_t L = (B + 7) / 8 * 8;
+  const int in_rows = weights ? kInRows : kInRows - MPC_NW;
+  const int out_rows = MPC_NOUT + (traj ? 2 * N : 0) + 1;
+  double *hi = h->h_io, *ho = h->h_io + kInRows * S;
+  double *di = h->d_io, *d_oblk = h->d_io + kInRows * S;
+  for (int q = 0; q < 6; q++) memcpy(hi + q * L, state + q * ld, sizeof(double) * B);
+  for (int q = 0; q < MPC_NCOEF; q++) memcpy(hi + (6 + q) * L, coeffs + q * ld, sizeof(double) * B);
+  memcpy(hi + 11 * L, yaw_lo, sizeof(double) * B);
+  memcpy(hi + 12 * L, yaw_hi, sizeof(double) * B);
+  if (weights) for (int q = 0; q < MPC_NW; q++) memcpy(hi + (13 + q) * L, weights + q * ld, sizeof(double) * B);
   hipStream_t s = h->stream;
-  for (int q = 0; q < 6; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_state + q * S, state + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
-  for (int q = 0; q < 5; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_coef + q * S, coeffs + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
-  MPC_HIP_CHECK(hipMemcpyAsync(d_ylo, yaw_lo, sizeof(double) * B, hipMemcpyHostToDevice, s));
-  MPC_HIP_CHECK(hipMemcpyAsync(d_yhi, yaw_hi, sizeof(double) * B, hipMemcpyHostToDevice, s));
-  if (weights) for (int q = 0; q < MPC_NW; q++) MPC_HIP_CHECK(hipMemcpyAsync(d_w + q * S, weights + q * ld, sizeof(double) * B, hipMemcpyHostToDevice, s));
-  int rc = mpc_solve_batch_device(h, B, S, d_state, d_coef, d_ylo, d_yhi, weights ? d_w : nullptr, d_o,
-                                  traj ? d_t : nullptr, h->d_status, h->d_iters, (void *)s);
+  MPC_HIP_CHECK(hipMemcpyAsync(di, hi, sizeof(double) * in_rows * L, hipMemcpyHostToDevice, s));
+  double *d_o = d_oblk, *d_t = d_o + MPC_NOUT * L;
+  int32_t *d_st = (int32_t *)(d_o + (out_rows - 1) * L), *d_it = d_st + L;
+  int rc = launch_solve<double>(h, B, L, L, di, di + 6 * L, di + 11 * L, di + 12 * L, weights ? di + 13 * L : nullptr, d_o,
+                        traj ? d_t : nullptr, d_st, d_it, (void *)s);
   if (rc != MPC_OK) return rc;
-  for (int q = 0; q < 9; q++) MPC_HIP_CHECK(hipMemcpyAsync(out + q * ld, d_o + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));
-  if (traj) for (int q = 0; q < 2 * N; q++) MPC_HIP_CHECK(hipMemcpyAsync(traj + q * ld, d_t + q * S, sizeof(double) * B, hipMemcpyDeviceToHost, s));
-  MPC_HIP_CHECK(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
-  if (iters) MPC_HIP_CHECK(hipMemcpyAsync(iters, h->d_iters, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(ho, d_o, sizeof(double) * out_rows * L, hipMemcpyDeviceToHost, s));
   MPC_HIP_CHECK(hipStreamSynchronize(s));
-  h->last_status = h->d_status; h->last_iters = h->d_iters;
+  for (int q = 0; q < MPC_NOUT; q++) memcpy(out + q * ld, ho + q * L, sizeof(double) * B);
+  if (traj) for (int q = 0; q < 2 * N; q++) memcpy(traj + q * ld, ho + (MPC_NOUT + q) * L, sizeof(double) * B);
+  const int32_t *h_st = (const int32_t *)(ho + (out_rows - 1) * L);
+  memcpy(status, h_st, sizeof(int32_t) * B);
+  if (iters) memcpy(iters, h_st + L, sizeof(int32_t) * B);
   return MPC_OK;
 }
 
@@ -539,23 +662,14 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
   if (!h || !st) return MPC_ERR_INVALID;
   memset(st, 0, sizeof(*st));
   st->batch = h->last_B;
-  if (h->last_B == 0 || !h->last_status) return MPC_OK;
-  MPC_HIP_CHECK(hipSetDevice(h->device));
-  MPC_HIP_CHECK(hipDeviceSynchronize());
-  std::vector<int32_t> s(h->last_B), it(h->last_B);
-  MPC_HIP_CHECK(hipMemcpy(s.data(), h->last_status, sizeof(int32_t) * h->last_B, hipMemcpyDeviceToHost));
-  MPC_HIP_CHECK(hipMemcpy(it.data(), h->last_iters, sizeof(int32_t) * h->last_B, hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < h->last_B; i++) {
-    switch (s[i]) {
-      case MPC_STATUS_SUCCESS: st->n_success++; break;
-      case MPC_STATUS_MAXITER: st->n_maxiter++; break;
-      case MPC_STATUS_LINESEARCH: st->n_linesearch++; break;
-      case MPC_STATUS_INFEASIBLE: st->n_infeasible++; break;
-      default: st->n_numeric++; break;
-    }
-    st->iter_sum += it[i];
-    if (it[i] > st->iter_max) st->iter_max = it[i];
-  }
+  if (h->last_B == 0 || !h->have_stats) return MPC_OK;
+  MPC_ON_DEVICE(h);
+  MPC_HIP_CHECK(hipEventSynchronize(h->ev_stats));
+  unsigned long long acc[8];
+  MPC_HIP_CHECK(hipMemcpy(acc, h->d_stats, sizeof(acc), hipMemcpyDeviceToHost));
+  st->n_success = (int64_t)acc[MPC_STATUS_SUCCESS]; st->n_maxiter = (int64_t)acc[MPC_STATUS_MAXITER];
+  st->n_linesearch = (int64_t)acc[MPC_STATUS_LINESEARCH]; st->n_infeasible = (int64_t)acc[MPC_STATUS_INFEASIBLE];
+  st->n_numeric = (int64_t)acc[4]; st->iter_sum = (int64_t)acc[5]; st->iter_max = (int32_t)acc[6];
   if (h->timed) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;

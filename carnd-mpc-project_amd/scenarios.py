@@ -127,13 +127,16 @@ def straight_line_batch(B, params, seed=DEFAULT_SEED):
     return {"state": state, "coeffs": coeffs, "yaw_lo": np.full(B, -0.1), "yaw_hi": np.full(B, 0.1)}
 
 
-def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_s=None, npts=6):
+def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_s=None, npts=6, filtered=True):
     """configs[2]: car placed on a random segment of the lake track, latency-compensated exactly as
     mpc_main.cpp:155-159 (mean solver time fixed to 0), next 6 waypoints, then MPC::run() preprocessing.
     Instances are redrawn when the reference's own road model does not hold for them: compensated speed
     above max_speed (the reference's NLP is infeasible), psi = 0 on a yaw bound, waypoints that are not
     strictly increasing in the vehicle-frame x (y = f(x) is then not a function: the track doubles back
-    inside the 6-point window), or a final fit error above Config::maxFitError (RoadGeometry.cpp:34)."""
+    inside the 6-point window), or a final fit error above Config::maxFitError (RoadGeometry.cpp:34).
+    The returned dict carries the counts ("drawn", "rejected": per criterion) so that callers can report them;
+    filtered=False keeps every draw with a finite fit (the unfiltered population: the solver then reports the
+    infeasible / non-converged ones through its per-instance status)."""
     wp = np.asarray(waypoints, dtype=np.float64)
     nwp = len(wp)
     g = _rng(seed, stream)
@@ -141,6 +144,8 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     keys = ("state", "coeffs", "yaw_lo", "yaw_hi", "ncoef", "max_yaw_change", "target_speed", "v0", "pose", "ptsx", "ptsy")
     acc = {k: [] for k in keys}
     need = B
+    drawn = 0
+    rej = {"speed_above_max": 0, "psi0_on_yaw_bound": 0, "waypoints_not_monotone_in_x": 0, "fit_error_above_max": 0, "nonfinite_fit": 0}
     while need > 0:
         n = max(int(need * 1.3) + 16, 64)
         k = g.integers(0, nwp, n)
@@ -169,9 +174,18 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
             psi = npsi
         idx = (k[:, None] + np.arange(npts)[None, :]) % nwp
         pre = run_preprocess(params, {"x": px, "y": py, "psi": psi, "v": v, "steer": steer}, wp[idx, 0], wp[idx, 1])
-        ok = (np.abs(v) < params.max_speed) & (pre["yaw_lo"] < -1e-3) & (pre["yaw_hi"] > 1e-3) & np.isfinite(pre["coeffs"]).all(axis=0)
-        ok &= (np.diff(pre["ptsx_vehicle"], axis=1) > 0).all(axis=1) & (pre["fiterr"] <= params.max_fit_error)
+        c_speed = np.abs(v) < params.max_speed
+        c_yaw = (pre["yaw_lo"] < -1e-3) & (pre["yaw_hi"] > 1e-3)
+        c_fin = np.isfinite(pre["coeffs"]).all(axis=0)
+        c_mono = (np.diff(pre["ptsx_vehicle"], axis=1) > 0).all(axis=1)
+        c_fit = pre["fiterr"] <= params.max_fit_error
+        ok = (c_speed & c_yaw & c_fin & c_mono & c_fit) if filtered else c_fin
         take = np.flatnonzero(ok)[:need]
+        used = (take[-1] + 1) if len(take) == need and len(take) else n      # draws looked at in this round
+        drawn += int(used)
+        for name, c in (("speed_above_max", c_speed), ("psi0_on_yaw_bound", c_yaw), ("waypoints_not_monotone_in_x", c_mono),
+                        ("fit_error_above_max", c_fit), ("nonfinite_fit", c_fin)):
+            rej[name] += int((~c[:used]).sum())
         acc["state"].append(pre["state"][:, take]); acc["coeffs"].append(pre["coeffs"][:, take])
         for kk in ("yaw_lo", "yaw_hi", "ncoef", "max_yaw_change", "target_speed"):
             acc[kk].append(pre[kk][take])
@@ -185,6 +199,8 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     out = {k: np.concatenate(acc[k], axis=1 if k in two_d else 0) for k in keys}
     for k in two_d:
         out[k] = np.ascontiguousarray(out[k])
+    out["drawn"] = drawn
+    out["rejected"] = rej if filtered else {"nonfinite_fit": rej["nonfinite_fit"]}
     return out
 
 

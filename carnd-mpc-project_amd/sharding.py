@@ -76,14 +76,14 @@ class PackedGather:
     """Zero-copy gather for equal shards (the weak-scaling bench, and any batch divisible by the world size).
 
     The solver writes its results straight into one packed float64 buffer per rank,
-        rows 0..8 out | 9..9+2N-1 trajectory (optional) | last row: status and iters as 2 x int32 per instance,
+        rows 0..8 out | 9..9+2N-1 trajectory (optional) | last row (two rows in float32): status and iters as 2 x int32 per instance,
     which is then gathered with ONE all_gather_into_tensor into full[rank, row, instance]: no packing kernels, no
     re-layout.  `slots` buffer sets alternate (slot = step % slots), and with overlap=True the collective is issued
     asynchronously: the gather of batch i runs while batch i+1 is being solved (its workgroups fit into the SIMDs
     that the solve frees in its tail), and a slot is reused only after its gather has completed.
     """
 
-    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2):
+    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2, dtype=None):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -91,19 +91,30 @@ class PackedGather:
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.ws = dist.get_world_size(group) if self.active else 1
         self.b, self.N, self.want_traj = int(b), int(N), bool(want_traj)
-        self.rows = 9 + (2 * self.N if want_traj else 0) + 1
+        self.dtype = dtype if dtype is not None else torch.float64      # float32 for an MPC_PRECISION_F32 handle
+        # status and iters are 2 x int32 per instance: one row of float64, two rows of float32
+        self.int_rows = 1 if self.dtype == torch.float64 else 2
+        self.rows = 9 + (2 * self.N if want_traj else 0) + self.int_rows
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self.overlap = bool(overlap) and self.nccl
         self.slots = int(slots)
-        self.pack = [torch.zeros((self.rows, self.b), dtype=torch.float64, device=device) for _ in range(self.slots)]
-        self.full = [torch.zeros((self.ws, self.rows, self.b), dtype=torch.float64, device=device) for _ in range(self.slots)] \
+        self.pack = [torch.zeros((self.rows, self.b), dtype=self.dtype, device=device) for _ in range(self.slots)]
+        self.full = [torch.zeros((self.ws, self.rows, self.b), dtype=self.dtype, device=device) for _ in range(self.slots)] \
             if self.active else [None] * self.slots
         self.work = [None] * self.slots
+        # which collective the timed region really ran: reported in bench.py's JSON line (never a silent fallback)
+        if not self.active:
+            self.mode = "none (single rank)"
+        elif self.nccl:
+            self.mode = "rccl all_gather_into_tensor, async (overlapped with the next solve)" if self.overlap else \
+                "rccl all_gather_into_tensor, synchronous"
+        else:
+            self.mode = "%s all_gather through host memory, synchronous (rehearsal backend)" % dist.get_backend(group)
 
     def outputs(self, slot):
         """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffer of `slot`."""
         p = self.pack[slot]
-        ints = p[self.rows - 1].view(self.torch.int32)            # 2*b int32 in the last row
+        ints = p[self.rows - self.int_rows:].reshape(-1).view(self.torch.int32)   # 2*b int32 in the last row(s)
         return {"out": p[0:9], "traj": p[9:9 + 2 * self.N] if self.want_traj else None,
                 "status": ints[:self.b], "iters": ints[self.b:2 * self.b]}
 
@@ -122,10 +133,11 @@ class PackedGather:
         if self.nccl:
             try:
                 w = dist.all_gather_into_tensor(self.full[slot], self.pack[slot], group=self.group, async_op=self.overlap)
-            except RuntimeError:
+            except RuntimeError as e:
                 if not self.overlap:
                     raise
-                self.overlap = False                      # fall back to the synchronous collective
+                self.overlap = False                      # fall back to the synchronous collective -- and say so
+                self.mode = "rccl all_gather_into_tensor, synchronous (async_op failed: %s)" % str(e).splitlines()[0][:80]
                 w = dist.all_gather_into_tensor(self.full[slot], self.pack[slot], group=self.group, async_op=False)
             self.work[slot] = w if self.overlap else None
         else:   # gloo (CPU tests, single-GPU rehearsal): through host memory, synchronous
@@ -145,6 +157,6 @@ class PackedGather:
             o = self.outputs(slot)
             return {k: (v[None] if v is not None else None) for k, v in o.items()}
         f = self.full[slot]
-        ints = f[:, self.rows - 1].contiguous().view(self.torch.int32).reshape(self.ws, 2 * self.b)
+        ints = f[:, self.rows - self.int_rows:].contiguous().reshape(self.ws, -1).view(self.torch.int32).reshape(self.ws, 2 * self.b)
         return {"out": f[:, 0:9], "traj": f[:, 9:9 + 2 * self.N] if self.want_traj else None,
                 "status": ints[:, :self.b], "iters": ints[:, self.b:]}

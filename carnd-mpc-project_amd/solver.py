@@ -43,6 +43,15 @@ class BatchedMPC:
     def N(self):
         return self.params.N
 
+    @property
+    def f32(self):
+        """True for a handle created with params.precision = MPC_PRECISION_F32 (float32 tensors in and out)."""
+        return self.params.precision == _abi.PRECISION_F32
+
+    def _dtype(self):
+        import torch
+        return torch.float32 if self.f32 else torch.float64
+
     def set_params(self, params: MpcParams):
         check(library().mpc_set_params(self._h, C.byref(params)), "mpc_set_params")
         self.params = params.copy()
@@ -50,37 +59,40 @@ class BatchedMPC:
     # -- device path (torch tensors resident in HBM) -------------------------
     def alloc_outputs(self, B, device, want_traj=False):
         import torch
+        dt = self._dtype()
         out = {
-            "out": torch.empty((_abi.NOUT, B), dtype=torch.float64, device=device),
+            "out": torch.empty((_abi.NOUT, B), dtype=dt, device=device),
             "status": torch.empty((B,), dtype=torch.int32, device=device),
             "iters": torch.empty((B,), dtype=torch.int32, device=device),
-            "traj": torch.empty((2 * self.N, B), dtype=torch.float64, device=device) if want_traj else None,
+            "traj": torch.empty((2 * self.N, B), dtype=dt, device=device) if want_traj else None,
         }
         return out
 
     def solve_torch(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False, outputs=None, stream=None):
-        """state [6,B], coeffs [5,B], yaw_lo/hi [B], weights [12,B] or None: float64 CUDA tensors.
-        Asynchronous on ``stream`` (default: torch's current stream). Returns the dict of output tensors."""
+        """state [6,B], coeffs [5,B], yaw_lo/hi [B], weights [12,B] or None: CUDA tensors, float64 (float32 for a
+        handle created with precision F32).  Asynchronous on ``stream`` (default: torch's current stream).  Returns the
+        dict of output tensors."""
         import torch
         B = state.shape[1]
+        dt = self._dtype()
         for name, t, rows in (("state", state, 6), ("coeffs", coeffs, 5)):
-            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape != (rows, B):
-                raise ValueError("%s must be a contiguous float64 CUDA tensor of shape (%d, B)" % (name, rows))
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous() or t.shape != (rows, B):
+                raise ValueError("%s must be a contiguous %s CUDA tensor of shape (%d, B)" % (name, dt, rows))
         for name, t in (("yaw_lo", yaw_lo), ("yaw_hi", yaw_hi)):
-            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.shape != (B,):
-                raise ValueError("%s must be a contiguous float64 CUDA tensor of shape (B,)" % name)
-        if weights is not None and (weights.dtype != torch.float64 or not weights.is_cuda or
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous() or t.shape != (B,):
+                raise ValueError("%s must be a contiguous %s CUDA tensor of shape (B,)" % (name, dt))
+        if weights is not None and (weights.dtype != dt or not weights.is_cuda or
                                     not weights.is_contiguous() or weights.shape != (_abi.NW, B)):
-            raise ValueError("weights must be a contiguous float64 CUDA tensor of shape (12, B)")
+            raise ValueError("weights must be a contiguous %s CUDA tensor of shape (12, B)" % dt)
         if outputs is None:
             outputs = self.alloc_outputs(B, state.device, want_traj)
         s = stream if stream is not None else torch.cuda.current_stream(state.device)
         traj = outputs.get("traj")
-        check(library().mpc_solve_batch_device(
-            self._h, B, B, state.data_ptr(), coeffs.data_ptr(), yaw_lo.data_ptr(), yaw_hi.data_ptr(),
-            weights.data_ptr() if weights is not None else None, outputs["out"].data_ptr(),
-            traj.data_ptr() if traj is not None else None, outputs["status"].data_ptr(),
-            outputs["iters"].data_ptr(), C.c_void_p(s.cuda_stream)), "mpc_solve_batch_device")
+        fn = library().mpc_solve_batch_device_f32 if self.f32 else library().mpc_solve_batch_device
+        check(fn(self._h, B, B, state.data_ptr(), coeffs.data_ptr(), yaw_lo.data_ptr(), yaw_hi.data_ptr(),
+                 weights.data_ptr() if weights is not None else None, outputs["out"].data_ptr(),
+                 traj.data_ptr() if traj is not None else None, outputs["status"].data_ptr(),
+                 outputs["iters"].data_ptr(), C.c_void_p(s.cuda_stream)), "mpc_solve_batch_device")
         return outputs
 
     def run_torch(self, pose, ptsx, ptsy, want_traj=False, want_pre=False, stream=None):

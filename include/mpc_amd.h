@@ -43,7 +43,7 @@ enum {
   MPC_ERR_INVALID = -1,     /* bad argument (NULL, N out of range, ld < B ...) */
   MPC_ERR_NO_DEVICE = -2,   /* no gfx950 device / HIP runtime unavailable */
   MPC_ERR_HIP = -3,         /* a HIP call failed; see mpc_last_error() */
-  MPC_ERR_UNSUPPORTED = -4, /* e.g. branch_mode LIVE or precision f32 not built */
+  MPC_ERR_UNSUPPORTED = -4, /* e.g. branch_mode LIVE, or run() with max_fit_order > 5 */
   MPC_ERR_IO = -5           /* config file unreadable / malformed */
 };
 
@@ -93,7 +93,7 @@ typedef struct MpcParams {
   /* solver controls (the reference's IPOPT option string, MPC.cpp:160-179, plus
    * the IPOPT defaults it leaves untouched) */
   int32_t branch_mode;       /* MPC_BRANCH_FROZEN: CppAD tape recorded once at the start point */
-  int32_t precision;         /* MPC_PRECISION_F64 */
+  int32_t precision;         /* MPC_PRECISION_F64 (default), or MPC_PRECISION_F32: see mpc_solve_batch_device_f32 */
   int32_t max_iter;          /* IPOPT default 3000; default here 200 */
   int32_t pass_cut;          /* two-phase solve: park instances still running after this many passes and finish them,
                               * re-packed, in a second launch (0 = single launch, the default) */
@@ -107,7 +107,8 @@ typedef struct MpcParams {
    * to, reproducible to ~1e-7 whatever the linear algebra (and a barrier parameter within 3x of the floor goes
    * to the floor directly).  Cost: +0.4 iterations per solve.  polish = 0 is IPOPT's own stopping rule. */
   double out_step_tol;       /* default 3e-7 (rad, m/s^2): leaves delta0 within 7e-8 and a0 within 2e-8 of the limit point */
-  double tol_f32;            /* "tol" of the MPC_PRECISION_F32 solver, default 1e-4 (see DESIGN.md, fp32 mode) */
+  double tol_f32;            /* "tol" of the MPC_PRECISION_F32 solver, default 5e-4 (barrier floor tol_f32/25, polish step
+                              * 0.6 tol_f32; see DESIGN.md, fp32 mode) */
   int32_t polish;            /* default 1 */
   int32_t reserved_i[3];
   double reserved_d[2];
@@ -132,7 +133,7 @@ int mpc_params_default(MpcParams *p);
 int mpc_params_load_json(const char *path, MpcParams *p);
 
 /* ---- lifetime -------------------------------------------------------------- */
-/* device < 0: current HIP device.  max_batch sizes the device workspace (3.7 KB per instance at N=10).
+/* device < 0: current HIP device.  max_batch sizes the device workspace (3.7 KB per instance at N=10; 2.0 KB in fp32).
  * A handle owns its workspace and launch state: calls on one handle must be ordered (one stream at a time).
  * To keep several batches in flight -- which is how to fill the device, see DESIGN.md section 6b -- create one
  * handle per stream. */
@@ -162,7 +163,19 @@ int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const double *st
                            const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                            const double *weights, double *out, double *traj, int32_t *status,
                            int32_t *iters, void *stream);
-/* Same, host pointers: copies in, launches, copies out, synchronises. */
+/* MPC_PRECISION_F32 (BASELINE.json configs[4]: "fp32 mixed precision"): the same solve for a handle created with
+ * params.precision = MPC_PRECISION_F32 -- fp32 inputs, outputs and workspace (136 B of HBM traffic per solve with
+ * per-instance weights and no trajectory).  Mixed precision: the interior-point iteration, the Riccati sweeps and the
+ * model's trigonometry run in fp32; the road polynomial (Horner at x ~ 80 m) and f(x) - y are evaluated in fp64, and
+ * residuals are formed as differences of neighbouring states first.  Tolerance tol_f32 (default 5e-4) instead of tol;
+ * against the fp64 path the answers agree to ~1e-3 rad in delta0 (tests/test_f32.py states the tolerances).
+ * An fp64 handle refuses this entry point and an fp32 handle refuses the double ones (MPC_ERR_INVALID); the run(),
+ * telemetry and rollout entry points are fp64 only. */
+int mpc_solve_batch_device_f32(MpcHandle *h, int64_t B, int64_t ld, const float *state,
+                               const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                               const float *weights, float *out, float *traj, int32_t *status,
+                               int32_t *iters, void *stream);
+/* Same as mpc_solve_batch_device, host pointers: one copy in, the launch, one copy out, synchronises. */
 int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *state,
                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                          const double *weights, double *out, double *traj, int32_t *status,

@@ -14,22 +14,21 @@
 #include "mpc_core.h"
 #include "mpc_run_core.h"
 
-extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, const double *state,
-                                   const double *coeffs, const double *yaw_lo, const double *yaw_hi,
-                                   const double *weights, double *out, double *traj, int32_t *status,
-                                   int32_t *iters) {
+template <class R>
+static int twin_solve(const MpcParams *p, int64_t B, int64_t ld, const R *state, const R *coeffs, const R *yaw_lo, const R *yaw_hi,
+                      const R *weights, R *out, R *traj, int32_t *status, int32_t *iters) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N;
-  std::vector<double> wsbuf((size_t)(N - 1) * mpc::STAGE_SZ_GLOBAL);
+  std::vector<R> wsbuf((size_t)(N - 1) * mpc::Fields<R>::STAGE_SZ);
   for (int64_t i = 0; i < B; i++) {
-    double st[6], cf[MPC_NCOEF], w[MPC_NW], o9[9];
-    std::vector<double> tr(2 * N);
+    R st[6], cf[MPC_NCOEF], w[MPC_NW], o9[9];
+    std::vector<R> tr(2 * N);
     for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
     for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
-    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : p->weights[q];
-    mpc::HostWorkspace ws{wsbuf.data()};
+    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)p->weights[q];
+    mpc::HostWorkspace<R> ws{wsbuf.data()};
     int it = 0;
-    int s = mpc::solve_instance(*p, ws, st, cf, yaw_lo[i], yaw_hi[i], w, o9, traj ? tr.data() : nullptr, &it);
+    int s = mpc::solve_instance<mpc::HostWorkspace<R>, R>(*p, ws, st, cf, yaw_lo[i], yaw_hi[i], w, o9, traj ? tr.data() : nullptr, &it);
     for (int q = 0; q < 9; q++) out[q * ld + i] = o9[q];
     if (traj) for (int q = 0; q < 2 * N; q++) traj[q * ld + i] = tr[q];
     status[i] = s;
@@ -38,8 +37,25 @@ extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, co
   return MPC_OK;
 }
 
+extern "C" int mpc_host_twin_solve(const MpcParams *p, int64_t B, int64_t ld, const double *state,
+                                   const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                   const double *weights, double *out, double *traj, int32_t *status,
+                                   int32_t *iters) {
+  return twin_solve<double>(p, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters);
+}
+/* the MPC_PRECISION_F32 solver (float I/O) */
+extern "C" int mpc_host_twin_solve_f32(const MpcParams *p, int64_t B, int64_t ld, const float *state,
+                                       const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                                       const float *weights, float *out, float *traj, int32_t *status,
+                                       int32_t *iters) {
+  return twin_solve<float>(p, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters);
+}
+
 extern "C" void mpc_host_twin_math(int64_t n, const double *x, double *sn, double *cs, double *rc) {
   for (int64_t i = 0; i < n; i++) { mpc::fsincos(x[i], &sn[i], &cs[i]); rc[i] = mpc::frcp(x[i]); }
+}
+extern "C" void mpc_host_twin_math_f32(int64_t n, const float *x, float *sn, float *cs, float *at) {
+  for (int64_t i = 0; i < n; i++) { mpc::fsincos(x[i], &sn[i], &cs[i]); at[i] = mpc::fatan(x[i]); }
 }
 extern "C" void mpc_host_twin_math2(int64_t n, const double *x, double *at, double *lg) {
   for (int64_t i = 0; i < n; i++) { at[i] = mpc::fatan(x[i]); lg[i] = mpc::flog(fabs(x[i])); }
@@ -85,17 +101,18 @@ extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t
                                           int32_t *was_parked) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N, M = N - 1;
-  using SV = mpc::Solver<mpc::HostWorkspace>;
-  std::vector<double> wsA((size_t)M * mpc::STAGE_SZ_GLOBAL), wsB((size_t)M * mpc::STAGE_SZ_GLOBAL, -7.0);
+  using SV = mpc::Solver<mpc::HostWorkspace<double>, double>;
+  using FD = mpc::Fields<double>;
+  std::vector<double> wsA((size_t)M * FD::STAGE_SZ), wsB((size_t)M * FD::STAGE_SZ, -7.0);
   for (int64_t i = 0; i < B; i++) {
     double st[6], cf[MPC_NCOEF], w[MPC_NW], park[SV::PARK_N];
     for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
     for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
     for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : p->weights[q];
-    SV A(*p, mpc::HostWorkspace{wsA.data()});
+    SV A(*p, mpc::HostWorkspace<double>{wsA.data()});
     int s = A.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0, passes = 0;
     SV *fin = &A;
-    SV Bs(*p, mpc::HostWorkspace{wsB.data()});
+    SV Bs(*p, mpc::HostWorkspace<double>{wsB.data()});
     was_parked[i] = 0;
     if (s == MPC_STATUS_SUCCESS) {
       A.begin(true);
@@ -113,9 +130,9 @@ extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t
           std::fill(wsB.begin(), wsB.end(), -7.0);                      /* nothing but the iterate slot comes along */
           Bs.setup(st, cf, yaw_lo[i], yaw_hi[i], w, false);
           Bs.unpark([&park](int q) -> double { return park[q]; }, attempt, it_total);
-          const int I = Bs.cur ? mpc::IT1 : mpc::IT0;
+          const int I = Bs.cur ? FD::IT1 : FD::IT0;
           for (int k = 0; k < M; k++)
-            for (int f = 0; f < mpc::IT_SZ; f++) wsB[(size_t)k * mpc::STAGE_SZ_GLOBAL + I + f] = wsA[(size_t)k * mpc::STAGE_SZ_GLOBAL + I + f];
+            for (int f = 0; f < FD::IT_SZ; f++) wsB[(size_t)k * FD::STAGE_SZ + I + f] = wsA[(size_t)k * FD::STAGE_SZ + I + f];
           cur = &Bs; was_parked[i] = 1;
         }
       }

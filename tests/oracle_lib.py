@@ -229,3 +229,19 @@ def telemetry_handler(cfg, tel6, ptsx, ptsy, extra=0.0, opt=None):
         pose = vehicle_move(cfg, pose, cfg.lookahead + extra)
     st, out8, tx, ty, pre, info = mpc_run(cfg, pose, ptsx, ptsy, opt)
     return st, -out8[4], compute_throttle(cfg, out8[5], out8[3]), out8
+
+
+def solve_chunk(job):
+    """Worker of bench.py's all-cores cpu_baseline leg (one process per core, one oracle thread each): solves the
+    instances of `job` = (config name, overrides, state [6,n], coeffs [5,n], yaw_lo [n], yaw_hi [n], weights [12,n] or None)
+    and returns how many it solved."""
+    name, over, state, coeffs, ylo, yhi, w = job
+    cfg = load_config(name, **over)
+    n = state.shape[1]
+    for i in range(n):
+        cfg.yaw_low, cfg.yaw_high = float(ylo[i]), float(yhi[i])
+        if w is not None:
+            for q in range(12):
+                cfg.weights[q] = float(w[q, i])
+        mpc_solve(cfg, state[:, i], coeffs[:, i])
+    return n

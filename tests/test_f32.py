@@ -1,0 +1,168 @@
+"""MPC_PRECISION_F32 (BASELINE.json configs[4]: "fp32 mixed precision, weight sweep"): the fp32 instantiation of the
+device solver against the fp64 oracle, with the tolerances stated in helpers.py (F32_TOL_*) and every instance's
+status accounted for.  The CPU tests run the test-only host build of the same header (tests/host_twin); the `gpu`
+tests run the HIP kernel through mpc_solve_batch_device_f32."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import (F32_TOL_ACCEL, F32_TOL_COST_REL, F32_TOL_STATE, F32_TOL_STEER, F32_TOL_TRAJ, oracle_solve_batch, twin_solve,
+                     twin_solve_f32, vp)
+
+
+def _f32_params(pkg, golden_dir, config="config-fast.json", **over):
+    p = pkg.params_from_json(os.path.join(golden_dir, config), **over)
+    p.precision = pkg.PRECISION_F32
+    return p
+
+
+def _check_f32(got, ref, what, n_expected):
+    """got: fp32 results (every instance), ref: fp64 results of the same instances.  100 % status accounting."""
+    assert (ref["status"] == 0).all(), (what, np.bincount(ref["status"]))
+    assert (got["status"] == 0).all(), (what, "fp32 statuses", np.bincount(got["status"]), np.where(got["status"] != 0)[0][:8])
+    assert len(got["status"]) == n_expected
+    g = got["out"].astype(np.float64)
+    d = np.abs(g - ref["out"])
+    rel_cost = d[8] / np.maximum(1.0, np.abs(ref["out"][8]))
+    assert d[6].max() <= F32_TOL_STEER, "%s max |d steer| = %g" % (what, d[6].max())
+    assert np.quantile(d[6], 0.99) <= 5e-4, "%s p99 |d steer| = %g" % (what, np.quantile(d[6], 0.99))
+    assert d[7].max() <= F32_TOL_ACCEL, "%s max |d accel| = %g" % (what, d[7].max())
+    assert np.quantile(d[7], 0.99) <= 2e-3, "%s p99 |d accel| = %g" % (what, np.quantile(d[7], 0.99))
+    assert d[:6].max() <= F32_TOL_STATE, "%s max |d step-1 state| = %g" % (what, d[:6].max())
+    assert rel_cost.max() <= F32_TOL_COST_REL, "%s max rel |d cost| = %g" % (what, rel_cost.max())
+    if got.get("traj") is not None and ref.get("traj") is not None:
+        assert np.abs(got["traj"].astype(np.float64) - ref["traj"]).max() <= F32_TOL_TRAJ
+    return d
+
+
+def test_f32_twin_weight_sweep_matches_fp64_oracle(pkg, host_twin, golden_dir, waypoints):
+    """configs[4] at CPU test size: lake-track states + per-instance weights (the values swept in the reference's
+    submission-report.md:303-319), fp32 solver against the dense fp64 oracle."""
+    params = _f32_params(pkg, golden_dir)
+    B = 192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=51)
+    w = pkg.scenarios.weight_sweep(B, params, seed=52)
+    r = twin_solve_f32(host_twin, params, b, weights=w)
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, range(B), weights=w)
+    _check_f32(r, ref, "weight sweep", B)
+    # the acceleration weight has no effect under the frozen tape: bitwise, also in fp32
+    w2 = w.copy(); w2[6] = 4321.0
+    r2 = twin_solve_f32(host_twin, params, b, weights=w2)
+    assert np.array_equal(r2["out"], r["out"])
+
+
+def test_f32_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, waypoints):
+    """4096 + 4096 instances (plain and weight sweep) against the fp64 build of the same solver, which the other tests
+    pin to the oracle at 1e-6: every instance converges in fp32 and stays inside the stated fp32 tolerances."""
+    params = _f32_params(pkg, golden_dir)
+    p64 = params.copy(); p64.precision = pkg.PRECISION_F64
+    for seed, weights in ((41, False), (43, True)):
+        b = pkg.scenarios.lake_track_batch(4096, params, waypoints, seed=seed)
+        w = pkg.scenarios.weight_sweep(4096, params, seed=44) if weights else None
+        r64 = twin_solve(host_twin, p64, b, weights=w, want_traj=False)
+        r32 = twin_solve_f32(host_twin, params, b, weights=w, want_traj=False)
+        _check_f32(r32, r64, "twin32 vs twin64 (weights=%s)" % weights, 4096)
+        assert r32["iters"].mean() < r64["iters"].mean()        # the looser tolerance is also fewer iterations
+
+
+def test_f32_math_kernels(host_twin):
+    """sin/cos/atan of the fp32 solver (polynomial kernels in mpc_core.h)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-4, 4, 20000), rng.uniform(-60, 60, 20000), rng.normal(0, 1e-3, 2000)]).astype(np.float32)
+    sn = np.zeros_like(x); cs = np.zeros_like(x); at = np.zeros_like(x)
+    host_twin.mpc_host_twin_math_f32(C.c_int64(len(x)), vp(x), vp(sn), vp(cs), vp(at))
+    xd = x.astype(np.float64)
+    assert np.max(np.abs(sn - np.sin(xd))) < 2.5e-7 and np.max(np.abs(cs - np.cos(xd))) < 2.5e-7
+    assert np.max(np.abs(at - np.arctan(xd))) < 2.5e-7
+
+
+def test_f32_edge_cases_twin(pkg, host_twin, golden_dir):
+    """Infeasible fixed initial state is flagged in fp32 too; the straight road with zero errors gives zero steering."""
+    params = _f32_params(pkg, golden_dir, "config-stable.json")
+    st = np.zeros((6, 3)); cf = np.zeros((5, 3))
+    st[3] = [60.0, 20.0, 20.0]; st[2, 1] = 0.2
+    b = {"state": st, "coeffs": cf, "yaw_lo": np.full(3, -0.1), "yaw_hi": np.full(3, 0.1)}
+    r = twin_solve_f32(host_twin, params, b)
+    assert list(r["status"]) == [3, 3, 0] and abs(r["out"][6, 2]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_f32_gpu_weight_sweep_matches_oracle(pkg, host_twin, golden_dir, waypoints):
+    """BASELINE.json configs[4] on the device, through mpc_solve_batch_device_f32: 16 384 instances with per-instance
+    weights; a sample against the dense fp64 oracle, ALL of them against the fp64 HIP path (itself pinned to the oracle at
+    1e-6 in test_gpu_parity.py), both builds of the kernel (one and two waves per SIMD) bitwise equal."""
+    import torch
+    dev = torch.device("cuda:0")
+    params = _f32_params(pkg, golden_dir)
+    p64 = params.copy(); p64.precision = pkg.PRECISION_F64
+    B = 16384
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=53)
+    w = pkg.scenarios.weight_sweep(B, params, seed=54)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    res = {}
+    old = os.environ.get("MPC_F32_OCC")
+    try:
+        for occ in ("2", "1"):
+            os.environ["MPC_F32_OCC"] = occ
+            with pkg.BatchedMPC(params, B, device=0) as mpc:
+                assert mpc.f32
+                f = torch.float32
+                r = mpc.solve_torch(t(b["state"], f), t(b["coeffs"], f), t(b["yaw_lo"], f), t(b["yaw_hi"], f), weights=t(w, f), want_traj=True)
+                torch.cuda.synchronize()
+                st = mpc.stats()
+                res[occ] = {k: v.cpu().numpy() for k, v in r.items()}
+                assert st.batch == B and st.n_success == int((res[occ]["status"] == 0).sum())
+                with pytest.raises(pkg.MpcError):      # an fp32 handle refuses fp64 tensors' entry point
+                    f64 = torch.float64
+                    pkg.library().mpc_solve_batch_device.restype = C.c_int
+                    from carnd_mpc_project_amd._abi import check
+                    check(pkg.library().mpc_solve_batch_device(mpc._h, 1, 1, *([t(np.zeros(8), f64).data_ptr()] * 9), None), "fp64 entry on fp32 handle")
+    finally:
+        if old is None:
+            os.environ.pop("MPC_F32_OCC", None)
+        else:
+            os.environ["MPC_F32_OCC"] = old
+    for k in ("out", "traj", "status", "iters"):
+        assert np.array_equal(res["2"][k], res["1"][k]), k
+    r32 = res["2"]
+    with pkg.BatchedMPC(p64, B, device=0) as mpc:
+        f = torch.float64
+        r = mpc.solve_torch(t(b["state"], f), t(b["coeffs"], f), t(b["yaw_lo"], f), t(b["yaw_hi"], f), weights=t(w, f), want_traj=True)
+        torch.cuda.synchronize()
+        r64 = {k: v.cpu().numpy() for k, v in r.items()}
+    _check_f32(r32, r64, "HIP fp32 vs HIP fp64", B)
+    idx = list(range(0, B, B // 96))
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
+    _check_f32({k: (v[..., idx] if v is not None else None) for k, v in r32.items()}, ref, "HIP fp32 vs oracle", len(idx))
+    # the CPU build of the same fp32 solver takes the same iteration path up to the rounding of the device's own math
+    rt = twin_solve_f32(host_twin, params, {k: v[..., :2048] for k, v in b.items() if k != "pose"}, weights=w[:, :2048], want_traj=False)
+    assert (rt["status"] == 0).all()
+    assert np.abs(rt["out"][6].astype(np.float64) - r32["out"][6, :2048]).max() <= F32_TOL_STEER
+
+
+@pytest.mark.gpu
+def test_f32_gpu_plain_batch_and_edges(pkg, golden_dir, waypoints):
+    """fp32 without per-instance weights, ragged batch size, status codes, empty batch."""
+    import torch
+    dev = torch.device("cuda:0")
+    params = _f32_params(pkg, golden_dir)
+    p64 = params.copy(); p64.precision = pkg.PRECISION_F64
+    B = 4096 + 37
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=55)
+    b["state"][3, 5] = 99.0                                                   # infeasible: v0 above max_speed
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    outs = {}
+    for p, dt in ((params, torch.float32), (p64, torch.float64)):
+        with pkg.BatchedMPC(p, B, device=0) as mpc:
+            r = mpc.solve_torch(t(b["state"], dt), t(b["coeffs"], dt), t(b["yaw_lo"], dt), t(b["yaw_hi"], dt), want_traj=True)
+            torch.cuda.synchronize()
+            outs[dt] = {k: v.cpu().numpy() for k, v in r.items()}
+            e = mpc.solve_torch(t(np.zeros((6, 0)), dt), t(np.zeros((5, 0)), dt), t(np.zeros(0), dt), t(np.zeros(0), dt))
+            assert e["out"].shape == (9, 0)
+    r32, r64 = outs[torch.float32], outs[torch.float64]
+    assert r32["status"][5] == 3 and r64["status"][5] == 3
+    keep = np.arange(B) != 5
+    _check_f32({k: v[..., keep] for k, v in r32.items()}, {k: v[..., keep] for k, v in r64.items()}, "plain batch", B - 1)
