@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol(pkg):
     from carnd_mpc_project_amd import _abi
     lib = pkg.library()
     header = open(os.path.join(_abi.ROOT, "include", "mpc_amd.h")).read()
-    declared = set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mpc_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
