@@ -81,7 +81,7 @@ def test_no_cpu_fallback_without_gpu(pkg, golden_dir):
 def test_invalid_params_rejected(pkg, golden_dir):
     p = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
     h = C.c_void_p()
-    for field, val in (("N", 2), ("N", 65), ("abi_version", 99), ("branch_mode", 1), ("precision", 1), ("max_iter", 0)):
+    for field, val in (("N", 2), ("N", 65), ("abi_version", 99), ("branch_mode", 1), ("precision", 7), ("max_iter", 0)):
         q = p.copy(); setattr(q, field, val)
         rc = pkg.library().mpc_create(C.byref(q), 0, 16, C.byref(h))
         assert rc in (-1, -4), (field, rc)
