@@ -1274,6 +1274,7 @@ struct Solver {
   int phase, iter, n_polish;
   bool ls_start, tiny;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
+  R out_prev;
   R tol, out_tol;  /* "tol" of this precision (MpcParams.tol or tol_f32) and the polish's step tolerance */
   R alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
   R theta_k, phi_k, pth, pdp, amin;   /* line-search state */
@@ -1451,14 +1452,16 @@ struct Solver {
         ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
       }
     }
-    if (accepted && sizeof(R) == 4 && n_polish > 0 && !(kkt_error(T, R(0.0)) <= R(10.0) * tol))
-      return MPC_STATUS_SUCCESS;   /* fp32: a polish step that throws the point out of the acceptable band (a slack of a few
-                                    * ulp collapsing) is dropped; the converged iterate stays */
+    /* fp32: a polish step that throws the point out of the acceptable band (a slack of a few ulp collapsing) is not taken
+     * at that length: the line search shortens it, and if no length works the converged iterate is returned as it is */
+    if (accepted && sizeof(R) == 4 && n_polish > 0 && !tiny && !(kkt_error(T, R(0.0)) <= R(10.0) * tol)) accepted = false;
     if (accepted) {
       if (!ftype) filter_add((R(1.0) - IC::gamma_theta) * theta_k, phi_k - IC::gamma_phi * theta_k);
       cur = 1 - cur;
       E = T;
-      out_step = alpha * T.du0;
+      /* fp32: the outputs must have been still for two steps in a row (steps are noisy and can be short for other reasons) */
+      out_step = sizeof(R) == 4 ? mpc_max(alpha * T.du0, out_prev) : alpha * T.du0;
+      out_prev = alpha * T.du0;
       ++iter;
       phase = PH_DIR;
       return MPC_RUNNING;

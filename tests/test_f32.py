@@ -29,6 +29,7 @@ def _check_f32(got, ref, what, n_expected):
     rel_cost = d[8] / np.maximum(1.0, np.abs(ref["out"][8]))
     assert d[6].max() <= F32_TOL_STEER, "%s max |d steer| = %g" % (what, d[6].max())
     assert np.quantile(d[6], 0.99) <= 5e-4, "%s p99 |d steer| = %g" % (what, np.quantile(d[6], 0.99))
+    assert np.quantile(d[6], 0.999) <= 2e-3, "%s p99.9 |d steer| = %g" % (what, np.quantile(d[6], 0.999))
     assert d[7].max() <= F32_TOL_ACCEL, "%s max |d accel| = %g" % (what, d[7].max())
     assert np.quantile(d[7], 0.99) <= 2e-3, "%s p99 |d accel| = %g" % (what, np.quantile(d[7], 0.99))
     assert d[:6].max() <= F32_TOL_STATE, "%s max |d step-1 state| = %g" % (what, d[:6].max())
