@@ -102,6 +102,56 @@ def test_run_batch_device_matches_oracle(pkg, golden_dir, waypoints):
         assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
 
 
+def _snapshots():
+    from helpers import TEST_CPP, TEST_CPP_COMMENTED
+    return [TEST_CPP] + TEST_CPP_COMMENTED
+
+
+def test_reference_snapshots_host_build(pkg, host_twin, golden_dir):
+    """The five telemetry snapshots of src/test.cpp (the active one, :45-50, and the four commented ones, :18-43) through
+    run(): fit order, cte0/epsi0, yaw bounds from the device header's pre-processing, then its solver, against the oracle."""
+    from helpers import twin_solve
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    orders = []
+    for s in _snapshots():
+        cfg = O.load_config("config-stable.json")
+        st, ref8, _, _, opre, _ = O.mpc_run(cfg, s["pose"], list(s["ptsx"]), list(s["ptsy"]))
+        assert st == 0
+        pose = np.array(s["pose"]).reshape(6, 1); px = np.array(s["ptsx"]).reshape(6, 1); py = np.array(s["ptsy"]).reshape(6, 1)
+        pre = np.zeros((15, 1)); nc = np.zeros(1, dtype=np.int32)
+        assert host_twin.mpc_host_twin_run_pre(C.byref(params), C.c_int64(1), C.c_int64(1), 6, vp(pose), vp(px), vp(py), vp(pre), vp(nc)) == 0
+        assert nc[0] == opre.nc and np.max(np.abs(pre[:6, 0] - np.array(list(opre.state)))) < 1e-9
+        assert abs(pre[11, 0] - opre.yaw_low) < 1e-9 and abs(pre[12, 0] - opre.yaw_high) < 1e-9
+        orders.append(int(nc[0]))
+        b = {"state": pre[:6], "coeffs": pre[6:11], "yaw_lo": pre[11], "yaw_hi": pre[12]}
+        r = twin_solve(host_twin, params, b)
+        assert r["status"][0] == 0
+        assert abs(r["out"][6, 0] - ref8[4] * cfg.max_steering) < 2e-6 or abs(opre.max_yaw_change) > cfg.steer_adj_thresh
+        assert np.max(np.abs(r["out"][[0, 1, 2, 3, 4, 5], 0] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
+    assert sorted(set(orders)) == [3, 4, 5]            # the adaptive fit stops at orders 2, 3 and 4 on these inputs (RoadGeometry.cpp:26-34)
+
+
+@pytest.mark.gpu
+def test_reference_snapshots_run_batch_device(pkg, golden_dir):
+    """The same five snapshots as ONE batch through mpc_run_batch_device."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    snaps = _snapshots()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.array(a, dtype=np.float64).T)).to(dev)
+    with pkg.BatchedMPC(params, 8, device=0) as mpc:
+        r = mpc.run_torch(t([s["pose"] for s in snaps]), t([s["ptsx"] for s in snaps]), t([s["ptsy"] for s in snaps]), want_pre=True)
+        torch.cuda.synchronize()
+        out8 = r["out8"].cpu().numpy(); status = r["status"].cpu().numpy()
+    assert (status == 0).all()
+    for i, s in enumerate(snaps):
+        cfg = O.load_config("config-stable.json")
+        st, ref8, _, _, _, _ = O.mpc_run(cfg, s["pose"], list(s["ptsx"]), list(s["ptsy"]))
+        assert st == 0
+        assert abs(out8[4, i] - ref8[4]) * params.max_steering < TOL_STEER and abs(out8[5, i] - ref8[5]) < TOL_ACCEL
+        assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
+
+
 # ---- N2: the telemetry handler around run() (src/mpc_main.cpp:126-174) ----------------------------------------------
 def _telemetry_from_pose(pose, rng):
     """Simulator-side telemetry whose handler-side pose is `pose` before latency compensation."""
