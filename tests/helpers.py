@@ -40,7 +40,7 @@ TOL_COST_REL = 1e-7
 F32_TOL_STEER = 5e-3     # rad (1 % of the steering range), every instance;  99.9 % of the instances: 2e-3;  99 %: 5e-4
 F32_TOL_ACCEL = 5e-2     # m/s^2 (0.4 % of the actuator range), every instance;  99 %: 2e-3
 F32_TOL_STATE = 5e-3     # m / rad / m/s, step-1 state
-F32_TOL_TRAJ = 0.3       # m, predicted trajectory: its far end is the least determined part of the solution (99 %: 2e-2)
+F32_TOL_TRAJ = 0.3       # m, predicted trajectory: its far end is the least determined part of the solution (99 %: 5e-2)
 F32_TOL_COST_REL = 1e-4
 
 
