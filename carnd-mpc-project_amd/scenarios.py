@@ -204,12 +204,16 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     return out
 
 
-def weight_sweep(B, params, seed=DEFAULT_SEED):
-    """configs[4]: per-instance Config::weights with the values swept in submission-report.md:303-319."""
+def weight_sweep(B, params, seed=DEFAULT_SEED, velocity_weights=(1.0, 100.0)):
+    """configs[4]: per-instance Config::weights with the values swept in submission-report.md:303-319.
+    The report also sweeps the velocity weight to 0 ("the vehicle decelerates", examples/velocity-weights.png): pass
+    velocity_weights=(0.0, 1.0, 100.0) for that.  It is left out of the default sweep because with no velocity term
+    the acceleration is bang-bang on a cost difference of ~1e-6: fp64 reproduces the reference's choice (tests), the
+    fp32 mode cannot be held to an a0 tolerance there."""
     g = _rng(seed, 5)
     w = np.tile(np.array([params.weights[i] for i in range(_abi.NW)])[:, None], (1, B))
     w[1] = g.choice([80.0, 100.0, 120.0, 1000.0], B)
-    w[2] = g.choice([1.0, 100.0], B)     # 0 makes the acceleration problem degenerate (no curvature in a)
+    w[2] = g.choice(list(velocity_weights), B)
     w[3] = g.choice([1.0, 300.0, 5000.0], B)
     w[6] = g.choice([0.0, 100.0, 10000.0], B)
     return np.ascontiguousarray(w)

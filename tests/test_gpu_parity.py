@@ -117,6 +117,20 @@ def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev
     assert np.array_equal(r2["out"], r["out"])
 
 
+def test_weight_sweep_with_zero_velocity_weight(pkg, golden_dir, waypoints, torch_dev):
+    """SURVEY.md section 8d Config 5 lists velocity weight 0 among the swept values: bang-bang accelerations."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 1024
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=46)
+    w = pkg.scenarios.weight_sweep(B, params, seed=47, velocity_weights=(0.0, 1.0, 100.0))
+    r = gpu_solve(pkg, params, b, torch_dev, weights=w)
+    assert (r["status"] == 0).all(), np.bincount(r["status"])
+    idx = list(np.where(w[2] == 0)[0][:96]) + list(range(0, B, 32))
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
+    assert (ref["status"] == 0).all()
+    assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "weights incl. w_v = 0")
+
+
 def test_scipy_goldens(pkg, golden_dir, torch_dev):
     gold = load_golden("scipy_cross_solve.json")
     for cfgname in ("config-stable.json", "config-fast.json"):

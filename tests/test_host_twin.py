@@ -71,6 +71,22 @@ def test_termination_polish_pins_weakly_determined_outputs(pkg, host_twin, golde
     assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.6
 
 
+def test_twin_weight_sweep_with_zero_velocity_weight(pkg, host_twin, golden_dir, waypoints):
+    """SURVEY.md section 8d, Config 5: the sweep including velocity weight 0 (the acceleration is then bang-bang between
+    maxDeceleration and maxAcceleration, examples/velocity-weights.png): fp64 agrees with the oracle to the stated 1e-6."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 96
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=26)
+    w = pkg.scenarios.weight_sweep(B, params, seed=27, velocity_weights=(0.0, 1.0, 100.0))
+    assert (w[2] == 0).sum() > 16
+    r = twin_solve(host_twin, params, b, weights=w)
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, range(B), weights=w)
+    assert (r["status"] == 0).all() and (ref["status"] == 0).all()
+    assert_parity(r["out"], ref["out"], r["traj"], ref["traj"], "weights incl. w_v = 0")
+    a0 = r["out"][7, w[2] == 0]
+    assert (a0 < params.max_deceleration + 1e-3).any()          # "the vehicle decelerates"
+
+
 def test_twin_per_instance_weights(pkg, host_twin, golden_dir, waypoints):
     """BASELINE.json configs[4]: per-instance Config::weights."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
