@@ -10,12 +10,12 @@ The directory is called ``carnd-mpc-project_amd`` (not importable as written);
 ``__graft_entry__.load_package()`` imports it under the name
 ``carnd_mpc_project_amd``.
 """
-from ._abi import (MpcParams, MpcBatchStats, MpcError, library, library_path, build_library,
+from ._abi import (MpcParams, MpcBatchStats, MpcWireTelemetry, MpcError, library, library_path, build_library,
                    params_default, params_from_json, STATUS_NAMES, PRECISION_F32, PRECISION_F64)
 from .solver import BatchedMPC
 from . import scenarios
 from . import sharding
 
-__all__ = ["MpcParams", "MpcBatchStats", "MpcError", "library", "library_path", "build_library",
+__all__ = ["MpcParams", "MpcBatchStats", "MpcWireTelemetry", "MpcError", "library", "library_path", "build_library",
            "params_default", "params_from_json", "BatchedMPC", "scenarios", "sharding", "STATUS_NAMES",
            "PRECISION_F32", "PRECISION_F64"]

@@ -48,6 +48,12 @@ class MpcParams(C.Structure):
         return q
 
 
+class MpcWireTelemetry(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("psi", C.c_double), ("speed", C.c_double),
+                ("steering_angle", C.c_double), ("throttle", C.c_double), ("npts", C.c_int32), ("reserved", C.c_int32),
+                ("ptsx", C.c_double * 8), ("ptsy", C.c_double * 8)]
+
+
 class MpcBatchStats(C.Structure):
     _fields_ = [("batch", C.c_int64), ("n_success", C.c_int64), ("n_maxiter", C.c_int64),
                 ("n_linesearch", C.c_int64), ("n_infeasible", C.c_int64), ("n_numeric", C.c_int64),
@@ -60,7 +66,8 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_last_error", "mpc_abi_version", "mpc_solve_batch_device", "mpc_solve_batch_host",
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
-           "mpc_solve_batch_device_f32"]
+           "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
+           "mpc_wire_telemetry_batch_host"]
 
 _lib = None
 
@@ -114,6 +121,12 @@ def library():
     L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
                                              [C.c_void_p])
     L.mpc_rollout_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
+    L.mpc_wire_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(MpcWireTelemetry)]
+    L.mpc_wire_format_steer.argtypes = [C.c_double, C.c_double, C.c_char_p, C.c_int64]
+    L.mpc_wire_format_steer.restype = C.c_int64
+    L.mpc_wire_format_manual.argtypes = [C.c_char_p, C.c_int64]
+    L.mpc_wire_format_manual.restype = C.c_int64
+    L.mpc_wire_telemetry_batch_host.argtypes = [C.c_void_p, C.c_int64, C.POINTER(MpcWireTelemetry), DP, C.c_double, DP, DP]
     if L.mpc_abi_version() != ABI_VERSION:
         raise MpcError("ABI version mismatch between %s and the Python binding" % path)
     _lib = L

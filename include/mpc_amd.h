@@ -211,6 +211,28 @@ int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, co
 int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int steps, double *state, const double *coeffs,
                              const double *yaw_lo, const double *yaw_hi, const double *weights, double *hist,
                              int32_t *status, int32_t *iters, void *stream);
+/* ---- the wire side of the handler (src/mpc_main.cpp:26-36, 81-222, DATA.md:5-16) --------
+ * Everything between the bytes of a simulator frame and the bytes of the reply; the WebSocket server itself is out of
+ * scope.  See csrc/mpc_wire.cpp. */
+enum { MPC_WIRE_MANUAL = 0, MPC_WIRE_TELEMETRY = 1, MPC_WIRE_IGNORE = 2 };
+typedef struct MpcWireTelemetry {
+  double x, y, psi, speed, steering_angle, throttle;   /* as sent: psi [rad], speed [mph], simulator's steering sign */
+  int32_t npts, reserved;
+  double ptsx[8], ptsy[8];                             /* global waypoints */
+} MpcWireTelemetry;
+/* One text frame `42["telemetry",{...}]`: MPC_WIRE_TELEMETRY and *out filled; MPC_WIRE_MANUAL when the frame carries no
+ * data (the reference answers `42["manual",{}]`, mpc_main.cpp:217-219); MPC_WIRE_IGNORE for anything that is not a "42"
+ * telemetry event (the reference stays silent); MPC_ERR_INVALID for a malformed telemetry object (the reference would
+ * throw out of json::parse). */
+int mpc_wire_parse(const char *frame, int64_t len, MpcWireTelemetry *out);
+/* The reply `42["steer",{...}]` byte for byte as mpc_main.cpp:183-197 builds it with nlohmann::json 2.1.1 (build without
+ * PLOT_TRAJECTORY).  Returns the length (NUL-terminated in buf), or MPC_ERR_INVALID if cap is too small. */
+int64_t mpc_wire_format_steer(double steering_angle, double throttle, char *buf, int64_t cap);
+int64_t mpc_wire_format_manual(char *buf, int64_t cap);
+/* B parsed frames, one per connection, through mpc_telemetry_batch_device (host arrays in and out).
+ * prev_throttle[B] or NULL: throttle of each connection's previous reply; cmd [2][B]: steering_angle row, throttle row. */
+int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcWireTelemetry *tel, const double *prev_throttle,
+                                  double extra_latency, double *cmd, int32_t *status);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
