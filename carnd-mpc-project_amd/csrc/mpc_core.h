@@ -274,6 +274,37 @@ struct TiledWorkspace {
   MPC_HD R sx(int buf, int k, int Fo, int j) const { return STAGING ? sl(buf, F::IT_SZ + j) : (R)it(k, 0, Fo + j); }
   MPC_HD R sg(int buf, int k, int J, int j) const { return STAGING ? sl(buf, F::IT_SZ + j) : (R)it(k, J, F::F_GK + j); }
 };
+
+/* The N-step variables of an instance RESIDENT IN LDS: for launches of at most a few thousand instances (one or a few
+ * per CU) the whole per-instance state -- two iterate slots, direction, gains: 3.7 KB at N = 10 in fp64 -- lives in the
+ * workgroup's LDS, [stage][field][LANES], LANES instances per wave.  No workspace traffic leaves the CU at all and a
+ * field is ~64 cycles away instead of an L2 / Infinity-Cache round trip, which is what a lone wave's stage step waits
+ * for in the streaming kernel (one MPC::solve() per telemetry message is the reference's own use: B = 1).
+ * The chip holds 160 KB x 256 of LDS = 10 900 instances this way (N = 10, fp64), far fewer than the lanes it has: large
+ * batches stream (TiledWorkspace).  Same Solver, same arithmetic: results are bitwise those of the streaming kernel. */
+template <class R, int LANES>
+struct LdsWorkspace {
+  using F = Fields<R>;
+  typedef typename AddrSpace<R>::l lreal;
+  lreal *base;   /* this workgroup's LDS */
+  int lane;      /* < LANES */
+  MPC_HD lreal &it(int k, int I, int f) const { return base[(unsigned)((k * F::STAGE_SZ + I + f) * LANES + lane)]; }
+  MPC_HD R getD(int k, int j) const { return it(k, 0, F::F_D + j); }
+  MPC_HD void setD(int k, int j, R v) const { it(k, 0, F::F_D + j) = v; }
+  template <int F0, int COUNT> MPC_HD void store_run(int k, int I, const R *v) const {
+    MPC_UNROLL
+    for (int j = 0; j < COUNT; j++) it(k, I, F0 + j) = v[j];
+  }
+  MPC_HD void stage_fetch_it(int, int, int) const {}
+  MPC_HD void stage_fetch_itf(int, int, int) const {}
+  MPC_HD void stage_fetch_d(int, int) const {}
+  MPC_HD void stage_fetch_g(int, int, int) const {}
+  template <int N> MPC_HD void stage_wait() const {}
+  MPC_HD void stage_drain() const {}
+  MPC_HD R sit(int, int k, int I, int j) const { return it(k, I, j); }
+  MPC_HD R sx(int, int k, int Fo, int j) const { return it(k, 0, Fo + j); }
+  MPC_HD R sg(int, int k, int J, int j) const { return it(k, J, F::F_GK + j); }
+};
 #endif
 
 /* ---- light-weight math (same code on device and in the test-only host build) ---- */

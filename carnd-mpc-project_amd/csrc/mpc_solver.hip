@@ -197,6 +197,41 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   }
 }
 
+/* Small launches: the N-step variables of every instance resident in LDS (mpc::LdsWorkspace), one instance per lane,
+ * LANES instances per workgroup (= per wave), no workspace in HBM at all.  Same solver, bitwise the same results. */
+template <class R, int LANES>
+__global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
+    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
+    const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
+    const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+  extern __shared__ double smem[];
+  using WS = mpc::LdsWorkspace<R, LANES>;
+  using SV = mpc::Solver<WS, R>;
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * LANES + lane;
+  if (lane >= LANES || i >= B) return;                 /* no barriers in this kernel: lanes are independent */
+  WS ws;
+  ws.base = (typename WS::lreal *)smem;
+  ws.lane = lane;
+  SV S(P, ws);
+  R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+  for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)P.weights[q];
+  int r = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, true);
+  if (r == MPC_STATUS_SUCCESS) r = S.solve();
+  R *o = out + i;
+  R *t = traj ? traj + i : nullptr;
+  const int64_t l = ldo;
+  S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
+  status[i] = r;
+  if (iters) iters[i] = S.iters;
+}
+
 /* MPC::run pre-processing, one instance per lane (mpc_run_core.h).  rows of `pre`: state 0..5, coeffs 6..10,
  * yaw_lo 11, yaw_hi 12, max_yaw_change 13, target_speed 14 */
 template <bool TELEMETRY>
@@ -310,6 +345,8 @@ struct MpcHandle {
   int64_t max_batch = 0;
   int64_t ws_stride = 0;   /* reals (double, or float for MPC_PRECISION_F32) per wavefront tile of the workspace */
   bool staging = true;
+  int lds_lanes = 0;       /* instances per workgroup of the LDS-resident kernel (0: N too large for it, or MPC_LDS=0) */
+  int64_t lds_max_batch = 0;   /* launches up to this size take the LDS-resident kernel: lds_lanes x number of CUs */
   bool occ2 = true;        /* fp32: the two-waves-per-SIMD build of the kernel (MPC_F32_OCC=1 selects the unconstrained one) */
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   void *ws = nullptr;
@@ -386,6 +423,23 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   } else MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
+  {
+    /* LDS-resident kernel: as many instances per workgroup as 160 KB hold (32, 16 or 8); one workgroup per CU */
+    const int64_t per_inst = mpc::workspace_fields_per_instance(p->N, f32) * (int64_t)(f32 ? sizeof(float) : sizeof(double));
+    for (int lanes : {32, 16, 8})
+      if (lanes * per_inst <= kLdsPerCu) { h->lds_lanes = lanes; break; }
+    if (const char *e = getenv("MPC_LDS")) if (atoi(e) == 0) h->lds_lanes = 0;
+    h->lds_max_batch = (int64_t)h->lds_lanes * prop.multiProcessorCount;
+    const void *fn = nullptr;
+    switch (h->lds_lanes) {
+      case 32: fn = f32 ? (const void *)mpc_solve_lds_kernel<float, 32> : (const void *)mpc_solve_lds_kernel<double, 32>; break;
+      case 16: fn = f32 ? (const void *)mpc_solve_lds_kernel<float, 16> : (const void *)mpc_solve_lds_kernel<double, 16>; break;
+      case 8: fn = f32 ? (const void *)mpc_solve_lds_kernel<float, 8> : (const void *)mpc_solve_lds_kernel<double, 8>; break;
+      default: break;
+    }
+    if (fn) MPC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    if (const char *e = getenv("MPC_LDS_MAX_BATCH")) h->lds_max_batch = atoll(e);
+  }
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -451,6 +505,26 @@ static int record_stats(MpcHandle *h, int64_t B, const int32_t *status, const in
   return MPC_OK;
 }
 
+template <class R, int LANES>
+static int launch_lds_n(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs, const R *yaw_lo,
+                        const R *yaw_hi, const R *weights, R *out, R *traj, int32_t *status, int32_t *iters, hipStream_t s) {
+  const size_t lds = (size_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4) * sizeof(R) * LANES;
+  const unsigned grid = (unsigned)((B + LANES - 1) / LANES);
+  hipLaunchKernelGGL((mpc_solve_lds_kernel<R, LANES>), dim3(grid), dim3(kBlock), lds, s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
+                     weights, out, traj, status, iters);
+  MPC_HIP_CHECK(hipGetLastError());
+  return MPC_OK;
+}
+template <class R>
+static int launch_lds(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs, const R *yaw_lo,
+                      const R *yaw_hi, const R *weights, R *out, R *traj, int32_t *status, int32_t *iters, hipStream_t s) {
+  switch (h->lds_lanes) {
+    case 32: return launch_lds_n<R, 32>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s);
+    case 16: return launch_lds_n<R, 16>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s);
+    default: return launch_lds_n<R, 8>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s);
+  }
+}
+
 /* the launch; ld = leading dimension of the inputs, ldo = of out/traj */
 template <class R>
 static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs,
@@ -479,6 +553,15 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
     MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 36 * h->io_stride));
     MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 2 * h->io_stride));
+  }
+  if (h->lds_lanes > 0 && B <= h->lds_max_batch) {
+    MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
+    const int rc = launch_lds<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, s);
+    if (rc != MPC_OK) return rc;
+    MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
+    return MPC_OK;
   }
   MpcTwoPhase T;
   T.ctl = h->d_counter; T.list_inst = h->d_list; T.list_src = h->d_list ? h->d_list + h->io_stride : nullptr;

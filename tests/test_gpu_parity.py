@@ -297,6 +297,41 @@ def test_staged_and_plain_kernels_are_bitwise_identical(pkg, golden_dir, waypoin
             os.environ["MPC_STAGING"] = old
 
 
+def test_lds_resident_kernel_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """Launches of up to (instances per workgroup) x (number of CUs) instances keep the N-step variables of every instance
+    in LDS (mpc::LdsWorkspace, no workspace in HBM); larger ones stream.  Same solver, same arithmetic: forcing the
+    streaming kernel (MPC_LDS=0) on the same batch must not change a bit -- fp64 and fp32, all three LDS packings
+    (32 / 16 / 8 instances per workgroup: N = 10, 25, 40), ragged sizes down to B = 1."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    old = os.environ.get("MPC_LDS")
+    try:
+        for N, dt, B in ((10, 0.1, 1), (10, 0.1, 2000 + 13), (25, 0.05, 777), (40, 0.025, 130)):
+            for prec in (pkg.PRECISION_F64, pkg.PRECISION_F32):
+                q = params.copy(); q.N = N; q.dt = dt; q.precision = prec
+                b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=79)
+                tdt = torch.float32 if prec == pkg.PRECISION_F32 else torch.float64
+                t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=tdt)
+                res = {}
+                for lds in ("1", "0"):
+                    os.environ["MPC_LDS"] = lds
+                    with pkg.BatchedMPC(q, B, device=0) as mpc:
+                        r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), want_traj=True)
+                        torch.cuda.synchronize()
+                        res[lds] = {k: v.cpu().numpy() for k, v in r.items()}
+                        st = mpc.stats()
+                        assert st.batch == B and st.iter_sum == int(res[lds]["iters"].sum())
+                for key in ("out", "traj", "status", "iters"):
+                    assert np.array_equal(res["1"][key], res["0"][key]), (N, prec, key)
+                if prec == pkg.PRECISION_F64:
+                    assert (res["1"]["status"] == 0).all()
+    finally:
+        if old is None:
+            os.environ.pop("MPC_LDS", None)
+        else:
+            os.environ["MPC_LDS"] = old
+
+
 def test_two_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
     """Parking unfinished instances after MPC_PASS_CUT passes and finishing them, re-packed, in a second launch must
     not change a single bit: the same arithmetic on the same state, only in another lane."""
