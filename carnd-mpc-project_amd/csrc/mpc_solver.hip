@@ -428,7 +428,12 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     const int64_t per_inst = mpc::workspace_fields_per_instance(p->N, f32) * (int64_t)(f32 ? sizeof(float) : sizeof(double));
     for (int lanes : {32, 16, 8})
       if (lanes * per_inst <= kLdsPerCu) { h->lds_lanes = lanes; break; }
-    if (const char *e = getenv("MPC_LDS")) if (atoi(e) == 0) h->lds_lanes = 0;
+    /* Measured on MI355X (tools/batch_sweep.py, same box, B = 1 ... 16 384): the LDS-resident kernel is 5-9 % SLOWER than the
+     * streaming kernel at every size -- a lone wave pays ~12 cycles of issue per ds_write_b64 for the 44 fields a stage
+     * stores per iteration, where the streaming kernel's global stores are fire-and-forget, and the stage step is bound by
+     * its dependent fp64 chain, not by the record's latency.  So it is opt-in: MPC_LDS=1. */
+    const char *e_lds = getenv("MPC_LDS");
+    if (!(e_lds && atoi(e_lds) == 1)) h->lds_lanes = 0;
     h->lds_max_batch = (int64_t)h->lds_lanes * prop.multiProcessorCount;
     const void *fn = nullptr;
     switch (h->lds_lanes) {

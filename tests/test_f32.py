@@ -117,11 +117,10 @@ def test_f32_gpu_weight_sweep_matches_oracle(pkg, host_twin, golden_dir, waypoin
                 st = mpc.stats()
                 res[occ] = {k: v.cpu().numpy() for k, v in r.items()}
                 assert st.batch == B and st.n_success == int((res[occ]["status"] == 0).sum())
-                with pytest.raises(pkg.MpcError):      # an fp32 handle refuses fp64 tensors' entry point
-                    f64 = torch.float64
-                    pkg.library().mpc_solve_batch_device.restype = C.c_int
-                    from carnd_mpc_project_amd._abi import check
-                    check(pkg.library().mpc_solve_batch_device(mpc._h, 1, 1, *([t(np.zeros(8), f64).data_ptr()] * 9), None), "fp64 entry on fp32 handle")
+                # an fp32 handle refuses the fp64 entry point (and says why)
+                z = t(np.zeros(16), torch.float64)
+                rc = pkg.library().mpc_solve_batch_device(mpc._h, 1, 1, *([C.c_void_p(z.data_ptr())] * 9), None)
+                assert rc == -1 and b"precision" in pkg.library().mpc_last_error()
     finally:
         if old is None:
             os.environ.pop("MPC_F32_OCC", None)

@@ -298,9 +298,9 @@ def test_staged_and_plain_kernels_are_bitwise_identical(pkg, golden_dir, waypoin
 
 
 def test_lds_resident_kernel_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
-    """Launches of up to (instances per workgroup) x (number of CUs) instances keep the N-step variables of every instance
-    in LDS (mpc::LdsWorkspace, no workspace in HBM); larger ones stream.  Same solver, same arithmetic: forcing the
-    streaming kernel (MPC_LDS=0) on the same batch must not change a bit -- fp64 and fp32, all three LDS packings
+    """With MPC_LDS=1, launches of up to (instances per workgroup) x (number of CUs) instances keep the N-step variables of
+    every instance in LDS (mpc::LdsWorkspace, no workspace in HBM).  Same solver, same arithmetic: against the streaming
+    kernel (the default; MPC_LDS=0) on the same batch not a bit may change -- fp64 and fp32, all three LDS packings
     (32 / 16 / 8 instances per workgroup: N = 10, 25, 40), ragged sizes down to B = 1."""
     import torch
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
