@@ -139,7 +139,7 @@ def test_f32_gpu_weight_sweep_matches_oracle(pkg, host_twin, golden_dir, waypoin
     ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
     _check_f32({k: (v[..., idx] if v is not None else None) for k, v in r32.items()}, ref, "HIP fp32 vs oracle", len(idx))
     # the CPU build of the same fp32 solver takes the same iteration path up to the rounding of the device's own math
-    rt = twin_solve_f32(host_twin, params, {k: v[..., :2048] for k, v in b.items() if k != "pose"}, weights=w[:, :2048], want_traj=False)
+    rt = twin_solve_f32(host_twin, params, {k: b[k][..., :2048] for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}, weights=w[:, :2048], want_traj=False)
     assert (rt["status"] == 0).all()
     assert np.abs(rt["out"][6].astype(np.float64) - r32["out"][6, :2048]).max() <= F32_TOL_STEER
 
