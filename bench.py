@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (handles on separate streams)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
+    ap.add_argument("--force-collective", action="store_true", help="one rank only: initialise RCCL with world size 1 and run the per-batch "
+                    "all_gather_into_tensor anyway (rehearses the collective path, its stream ordering and overlap, on a one-GPU box)")
     ap.add_argument("--stub", default="", help="TEST ONLY (tests/test_bench_spawn.py): 'host_twin' replaces the device solve by "
                     "the CPU build of the solver header so that the multi-process plumbing can be exercised without a GPU; "
                     "the line it prints is marked as a stub and is not a measurement")
@@ -183,9 +185,10 @@ def main():
     else:
         dev = torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -226,7 +229,7 @@ def main():
     # results go straight into a packed buffer that is gathered with one all_gather_into_tensor; two buffer sets
     # alternate so that the gather of batch i overlaps the solve of batch i+1 (sharding.PackedGather)
     pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
-                                   slots=max(2, nfl), dtype=tdt)
+                                   slots=max(2, nfl), dtype=tdt, force=args.force_collective)
 
     def sync_all():
         if stub is None:

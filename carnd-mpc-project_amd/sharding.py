@@ -83,12 +83,13 @@ class PackedGather:
     that the solve frees in its tail), and a slot is reused only after its gather has completed.
     """
 
-    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2, dtype=None):
+    def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2, dtype=None, force=False):
         import torch
         if dist is None:
             import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # force=True runs the collective even with a single rank (rehearsal of the RCCL path on a one-GPU box)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.ws = dist.get_world_size(group) if self.active else 1
         self.b, self.N, self.want_traj = int(b), int(N), bool(want_traj)
         self.dtype = dtype if dtype is not None else torch.float64      # float32 for an MPC_PRECISION_F32 handle
