@@ -160,6 +160,12 @@ def main():
     if args.gpus > 1 and world_env == 1:
         sys.exit(spawn_ranks(args))                                # before anything touches the GPU
 
+    # stdout carries rank 0's ONE JSON line and nothing else: RCCL and gloo print banners to fd 1 when a communicator is
+    # created, so everything below writes to stderr and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import __graft_entry__ as G
@@ -410,8 +416,8 @@ def main():
         res["max_abs_dsteer_vs_oracle"] = worst_steer
         res["max_abs_daccel_vs_oracle"] = worst_acc
         res["parity_sample"] = n_done
-    print(json.dumps(res))
     sys.stdout.flush()
+    os.write(json_fd, (json.dumps(res) + "\n").encode())
     for h in mpcs:
         h.close()
     if dist is not None:
