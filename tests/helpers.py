@@ -28,6 +28,16 @@ TEST_CPP_COMMENTED = [
     dict(ptsx=_WP_D[0], ptsy=_WP_D[1], pose=[-61.97283, 93.53992, 3.857562, 33.06046, 0.0, 0.0]),        # test.cpp:38-43
 ]
 
+# Instances that leave the central path: the UNFILTERED lake-track draw (seed 45, 16 384 instances,
+# config-fast.json) contains the situations the generator normally rejects -- waypoint windows that double back, so that
+# the "road" is a degree-4 fit with a cte of hundreds of metres.  On those the line search runs out of step length, i.e.
+# where IPOPT would enter its restoration phase (not restated; stand-in: one restart with zero multipliers), or the
+# iteration cap strikes.  index -> (status, iterations) that oracle and device solver BOTH report, with the same point:
+OFF_PATH_BATCH = dict(config="config-fast.json", B=16384, seed=45)
+OFF_PATH_INSTANCES = {235: (2, 47), 2080: (2, 43), 11515: (2, 8), 12533: (1, 376),          # restoration stand-in fails / cap
+                      1340: (0, 197), 8676: (0, 128), 9386: (0, 123), 9966: (0, 109), 10296: (0, 104)}   # converge after >100 iterations
+# 6049 (cte0 = -1143 m) converges in both solvers, to DIFFERENT local minima (delta0 -0.436 vs +0.042): not a parity case.
+
 # stated fp64 tolerances (SURVEY.md section 8d / BASELINE.md section 4)
 TOL_STEER = 1e-6   # rad, delta0
 TOL_ACCEL = 1e-6   # m/s^2, a0

@@ -131,6 +131,28 @@ def test_weight_sweep_with_zero_velocity_weight(pkg, golden_dir, waypoints, torc
     assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "weights incl. w_v = 0")
 
 
+def test_instances_that_leave_the_central_path(pkg, golden_dir, waypoints, torch_dev):
+    """The named off-path instances (helpers.OFF_PATH_INSTANCES) on the device: where IPOPT would enter its restoration
+    phase, and where the iteration cap strikes, the HIP path reports the oracle's status and returns the oracle's point."""
+    from helpers import OFF_PATH_BATCH, OFF_PATH_INSTANCES
+    params = pkg.params_from_json(os.path.join(golden_dir, OFF_PATH_BATCH["config"]))
+    b = pkg.scenarios.lake_track_batch(OFF_PATH_BATCH["B"], params, waypoints, seed=OFF_PATH_BATCH["seed"], filtered=False)
+    with pkg.BatchedMPC(params, OFF_PATH_BATCH["B"], device=0) as mpc:
+        r = gpu_solve(pkg, params, b, torch_dev, mpc=mpc, want_traj=False)
+        st = mpc.stats()
+    counts = np.bincount(r["status"], minlength=5)
+    assert counts.sum() == OFF_PATH_BATCH["B"] and counts[3] == 0 and counts[4] == 0
+    assert (st.n_success, st.n_maxiter, st.n_linesearch) == (int(counts[0]), int(counts[1]), int(counts[2]))
+    idx = sorted(OFF_PATH_INSTANCES)
+    ref = oracle_solve_batch(O.load_config(OFF_PATH_BATCH["config"]), b, idx, opt=O.default_options(max_iter=params.max_iter))
+    for j, i in enumerate(idx):
+        want_status, want_iters = OFF_PATH_INSTANCES[i]
+        assert ref["status"][j] == want_status
+        assert r["status"][i] == want_status, (i, r["status"][i])
+        assert abs(int(r["iters"][i]) - want_iters) <= (0 if want_status == 1 else 3), (i, r["iters"][i])   # the device's own rcp/sincos may shift a step
+        assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, j])) < (1e-6 if want_status == 0 else 1e-4), i
+
+
 def test_scipy_goldens(pkg, golden_dir, torch_dev):
     gold = load_golden("scipy_cross_solve.json")
     for cfgname in ("config-stable.json", "config-fast.json"):

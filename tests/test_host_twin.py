@@ -71,6 +71,26 @@ def test_termination_polish_pins_weakly_determined_outputs(pkg, host_twin, golde
     assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.6
 
 
+def test_instances_that_leave_the_central_path(pkg, host_twin, golden_dir, waypoints):
+    """Where IPOPT would enter its restoration phase (src/control/MPC.cpp:290-292) and where the iteration cap strikes:
+    named instances of the unfiltered draw.  The device solver (CPU build) and the oracle report the SAME status, the same
+    iteration count and the same point -- the point is the last iterate, which is what the reference returns as well
+    (it prints the status and returns solution.x, MPC.cpp:295-303)."""
+    from helpers import OFF_PATH_BATCH, OFF_PATH_INSTANCES
+    params = pkg.params_from_json(os.path.join(golden_dir, OFF_PATH_BATCH["config"]))
+    b = pkg.scenarios.lake_track_batch(OFF_PATH_BATCH["B"], params, waypoints, seed=OFF_PATH_BATCH["seed"], filtered=False)
+    r = twin_solve(host_twin, params, b, want_traj=False)
+    counts = np.bincount(r["status"], minlength=5)
+    assert list(counts) == [16380, 1, 3, 0, 0]                       # every instance accounted for
+    idx = sorted(OFF_PATH_INSTANCES)
+    ref = oracle_solve_batch(O.load_config(OFF_PATH_BATCH["config"]), b, idx, opt=O.default_options(max_iter=params.max_iter))
+    for j, i in enumerate(idx):
+        st, it = OFF_PATH_INSTANCES[i]
+        assert (r["status"][i], r["iters"][i]) == (st, it), (i, r["status"][i], r["iters"][i])
+        assert ref["status"][j] == st and ref["iters"][j] == it, (i, ref["status"][j], ref["iters"][j])
+        assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, j])) < 1e-6, i
+
+
 def test_twin_weight_sweep_with_zero_velocity_weight(pkg, host_twin, golden_dir, waypoints):
     """SURVEY.md section 8d, Config 5: the sweep including velocity weight 0 (the acceleration is then bang-bang between
     maxDeceleration and maxAcceleration, examples/velocity-weights.png): fp64 agrees with the oracle to the stated 1e-6."""

@@ -10,10 +10,11 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-I" + ROOT + "/carnd-mpc-project_amd/csrc", "--cuda-device-only", "-S", "-o", s_path,
                        ROOT + "/carnd-mpc-project_amd/csrc/mpc_solver.hip"] + os.environ.get("EXTRA", "").split(), stderr=subprocess.DEVNULL)
 txt = open(s_path).read()
-m = re.search(r"^_ZN12_GLOBAL__N_116mpc_solve_kernelILb1E.*?s_endpgm", txt, re.S | re.M)
+KERNEL = os.environ.get("KERNEL", "_ZN12_GLOBAL__N_116mpc_solve_kernelILb1EdLi1E")   # <STAGING=true, double, OCC=1>; fp32: ...ILb1EfLi2E
+m = re.search(r"^" + KERNEL + r".*?s_endpgm", txt, re.S | re.M)
 k = m.group(0).split("\n")
-meta = re.findall(r"; (NumVgprs|NumAgprs|ScratchSize|codeLenInByte|Occupancy)[:=]? *=? *(\d+)", txt[m.end():m.end() + 3000])
-print("solve kernel <STAGING=true>:", dict(meta[:5]))
+meta = re.findall(r"; (NumVgprs|NumAgprs|TotalNumVgprs|ScratchSize|codeLenInByte|Occupancy)[:=]? *=? *(\d+)", txt[m.end():m.end() + 12000])
+print(KERNEL, dict(meta[:6]))
 depth = 0; label = ""; cnt = 0; out = []
 stats = {"scratch_load": 0, "scratch_store": 0, "valu": 0, "accvgpr": 0, "dma": 0}
 deep = 0
