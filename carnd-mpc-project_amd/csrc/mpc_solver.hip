@@ -64,8 +64,10 @@ template <class R> constexpr size_t staging_lds_bytes() { return 2u * mpc::Field
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MPC_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)   /* over the active lanes of the wave */
+#define MPC_WAVE_COUNT(p) __builtin_popcountll(__builtin_amdgcn_ballot_w64(p))
 #else
 #define MPC_WAVE_ANY(p) (p)
+#define MPC_WAVE_COUNT(p) ((p) ? 1 : 0)
 #endif
 
 /* Persistent form: a wave does not own 64 fixed instances.  Every lane takes the next unsolved instance from a
@@ -92,6 +94,11 @@ struct MpcTwoPhase {
   const void *src_ws;      /* phase B: workspace of phase A */
   int32_t pass_cut;        /* phase A: park after this many passes (0 = never) */
   int32_t resume;          /* 1 = phase B */
+  /* Hand-over policy.  Writing a finished instance out and fetching the next one (set-up, start point: 270 stores) is
+   * divergent code that the whole wave pays for, ~4 us per event against ~80 us per pass, and with 64 lanes finishing at
+   * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
+   * waiting, or `refill_wait` passes have gone by, or nothing else is running; then all of them are served at once. */
+  int32_t refill_min, refill_wait;
 };
 
 /* OCC = waves per SIMD the register allocation is held to: the fp64 solver needs ~380 registers (1); the fp32 solver
@@ -113,58 +120,67 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
   int64_t i = 0;
-  bool have = false, more = true;      /* holds an instance / may still get one */
-  int attempt = 0, it_total = 0, passes = 0;
+  bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
+  int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0;
   const int64_t n_work = T.resume ? (int64_t)T.ctl[1] : B;
   for (;;) {
-    if (!have && more) {
-      const int64_t pos = (int64_t)atomicAdd(T.ctl + (T.resume ? 2 : 0), 1);
-      more = pos < n_work;
-      if (more) {
-        i = T.resume ? (int64_t)T.list_inst[pos] : pos;
-        R st[6], cf[MPC_NCOEF], w[MPC_NW];
-#pragma unroll
-        for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
-#pragma unroll
-        for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
-        if (weights) {
-#pragma unroll
-          for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
-        } else {
-#pragma unroll
-          for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
-        }
-        const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
-        if (T.resume) {
-          /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
-          const double *pk = T.park + pos;
-          const int64_t lp = T.ld_park;
-          S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
-          const int src = T.list_src[pos];
-          WS wsrc = ws;
-          wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
-          wsrc.lane = src & 63;
-          const int I = S.cur ? FL::IT1 : FL::IT0;
-          for (int k = 0; k < P.N - 1; ++k) {
-            R rec[FL::IT_SZ];
-#pragma unroll
-            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
-            ws.template store_run<0, FL::IT_SZ>(k, I, rec);
-          }
-          passes = 0; have = true;
-        } else if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
-        else {
-          /* rejected at set-up (initial state outside its own bounds): report the start point, ask again */
+    /* ---- hand-over point (wave-uniform decision, see MpcTwoPhase) ---- */
+    const int n_wait = MPC_WAVE_COUNT(fin || (!have && more));
+    if (n_wait > 0) {
+      if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait) {
+        waited = 0;
+        if (fin) {
           R *o = out + i;
           R *t = traj ? traj + i : nullptr;
           const int64_t l = ldo;
           S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
-          status[i] = s0;
-          if (iters) iters[i] = 0;
+          status[i] = fin_status;
+          if (iters) iters[i] = S.iters + it_total;
+          fin = false;
         }
-      }
+        if (!have && more) {
+          const int64_t pos = (int64_t)atomicAdd(T.ctl + (T.resume ? 2 : 0), 1);
+          more = pos < n_work;
+          if (more) {
+            i = T.resume ? (int64_t)T.list_inst[pos] : pos;
+            R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+            for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+#pragma unroll
+            for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+            if (weights) {
+#pragma unroll
+              for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
+            } else {
+#pragma unroll
+              for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
+            }
+            const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
+            if (T.resume) {
+              /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
+              const double *pk = T.park + pos;
+              const int64_t lp = T.ld_park;
+              S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
+              const int src = T.list_src[pos];
+              WS wsrc = ws;
+              wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
+              wsrc.lane = src & 63;
+              const int I = S.cur ? FL::IT1 : FL::IT0;
+              for (int k = 0; k < P.N - 1; ++k) {
+                R rec[FL::IT_SZ];
+#pragma unroll
+                for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
+                ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+              }
+              passes = 0; have = true;
+            } else if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
+            else { it_total = 0; S.iters = 0; fin = true; fin_status = s0; }   /* rejected at set-up (initial state outside its own
+                                                                               * bounds): the start point is reported at the next hand-over */
+          }
+        }
+      } else ++waited;
     }
-    if (!MPC_WAVE_ANY(have || more)) break;
+    if (!MPC_WAVE_ANY(have || more || fin)) break;
     if (have) {
       const int r = S.step();
       ++passes;
@@ -174,15 +190,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           attempt = 1; it_total += S.iters;
           S.start_point();
           S.begin(false);
-        } else {
-          R *o = out + i;
-          R *t = traj ? traj + i : nullptr;
-          const int64_t l = ldo;
-          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
-          status[i] = r;
-          if (iters) iters[i] = S.iters + it_total;
-          have = false;
-        }
+        } else { fin = true; fin_status = r; have = false; }
       } else if (T.pass_cut > 0 && passes >= T.pass_cut && S.phase == SV::PH_DIR) {
         /* still running: park it for phase B */
         const int64_t pos = (int64_t)atomicAdd(T.ctl + 1, 1);
@@ -364,6 +372,7 @@ struct MpcHandle {
   int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
+  int refill_min = 8, refill_wait = 4;   /* hand-over policy of the persistent kernel (MpcTwoPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
   /* two-phase solve: second workspace, parked-instance list and scalars (allocated on first use) */
   int pass_cut = 0;           /* MpcParams.pass_cut, or MPC_PASS_CUT in the environment (0 = single launch) */
   int64_t two_phase_min = 8192;
@@ -460,6 +469,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   h->pass_cut = p->pass_cut > 0 ? p->pass_cut : 0;
   if (const char *e3 = getenv("MPC_PASS_CUT")) { h->pass_cut = atoi(e3); if (h->pass_cut < 0) h->pass_cut = 0; }
+  if (const char *e4 = getenv("MPC_REFILL_MIN")) { h->refill_min = atoi(e4); if (h->refill_min < 1) h->refill_min = 1; }
+  if (const char *e5 = getenv("MPC_REFILL_WAIT")) { h->refill_wait = atoi(e5); if (h->refill_wait < 0) h->refill_wait = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
   *out = h;
   return MPC_OK;
@@ -571,6 +582,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   MpcTwoPhase T;
   T.ctl = h->d_counter; T.list_inst = h->d_list; T.list_src = h->d_list ? h->d_list + h->io_stride : nullptr;
   T.park = h->d_park; T.ld_park = h->io_stride; T.src_ws = h->ws; T.pass_cut = two ? h->pass_cut : 0; T.resume = 0;
+  T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
   int32_t *it_out = iters ? iters : h->d_iters;
   MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));

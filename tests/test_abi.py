@@ -85,3 +85,31 @@ def test_invalid_params_rejected(pkg, golden_dir):
         q = p.copy(); setattr(q, field, val)
         rc = pkg.library().mpc_create(C.byref(q), 0, 16, C.byref(h))
         assert rc in (-1, -4), (field, rc)
+
+
+@pytest.mark.parametrize("name", ["config-stable.json", "config-fast.json", "config-no-latency.json"])
+def test_params_from_json_against_a_third_reader(pkg, golden_dir, name):
+    """mpc_params.cpp and the oracle's reader are both purpose-built flat-JSON parsers (a shared mistake would pass the
+    test above): here the file goes through Python's json module and Config::load's rules (src/utils/Config.cpp:31-87) are
+    applied in numpy."""
+    import json
+    import numpy as np
+    j = json.load(open(os.path.join(golden_dir, name)))
+    mph = lambda x: x * 1609.34 / 3600.0                                  # utils.h:11-13
+    p = pkg.params_from_json(os.path.join(golden_dir, name))
+    assert (p.N, p.dt, p.latency_ms, p.max_fit_order) == (j["N"], j["dt"], j["latency"], j["max polynomial fitting order"])
+    assert p.lookahead == pytest.approx(j["latency"] * 1e-3, abs=1e-15) and p.ipopt_timeout == j["ipopt timeout"]
+    assert p.max_fit_error == j["max polynomial fitting error"] and p.Lf == j["Lf"]
+    assert p.max_steering == pytest.approx(np.deg2rad(j["max steering"]), rel=1e-15)
+    assert p.max_acceleration == pytest.approx(mph(j["max acceleration"]), rel=1e-15)
+    assert p.max_deceleration == pytest.approx(mph(j["max deceleration"]), rel=1e-15)
+    assert p.max_speed == pytest.approx(mph(j["max speed"]), rel=1e-15)
+    assert (p.epsi_panic, p.cte_panic, p.steer_adj_thresh) == (j["epsi panic"], j["cte panic"], j["steer adjustment threshold"])
+    assert p.steer_adj_ratio == min(max(j["steer adjustment ratio"], 0.0), 0.1)
+    assert list(p.weights)[:12] == j["weights"][:12] and len(j["weights"]) > 11
+    scale = mph(j["max speed"]) / mph(100)                                 # Config.cpp:65
+    for key, tab, n_tab, skey, stab, n_stab in (("steers", p.steers, p.n_steers, "steer speeds", p.steer_speeds, p.n_steer_speeds),
+                                                ("yaw changes", p.yaw_changes, p.n_yaw_changes, "yaw change speeds", p.yaw_change_speeds, p.n_yaw_change_speeds)):
+        assert n_tab == len(j[key]) and list(tab)[:n_tab] == j[key]
+        want = [mph(s) * scale if scale > 1 else min(mph(s), mph(j["max speed"])) for s in j[skey]]
+        assert n_stab == len(want) and np.allclose(list(stab)[:n_stab], want, rtol=1e-15)
