@@ -372,7 +372,7 @@ struct MpcHandle {
   int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
-  int refill_min = 8, refill_wait = 4;   /* hand-over policy of the persistent kernel (MpcTwoPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
+  int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcTwoPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
   /* two-phase solve: second workspace, parked-instance list and scalars (allocated on first use) */
   int pass_cut = 0;           /* MpcParams.pass_cut, or MPC_PASS_CUT in the environment (0 = single launch) */
   int64_t two_phase_min = 8192;
