@@ -305,6 +305,7 @@ def main():
     outs = pg.outputs(last)
     status = outs["status"].cpu().numpy()
     out_np = outs["out"].cpu().numpy()
+    iters_np = outs["iters"].cpu().numpy()
     # the gathered copy of this rank's shard must be what the solver wrote
     g = pg.result(last)
     gather_ok = bool(torch.equal(g["out"][rank if dist is not None else 0], outs["out"]) and
@@ -344,6 +345,12 @@ def main():
         "converged_fraction": float((status == 0).mean()),
         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
         "mean_iterations": mean_iters, "max_iterations": int(stats.iter_max),
+        # per-instance interior-point iterations of the last batch: the launch lasts as long as its slowest instance
+        "iteration_quantiles": {q: int(np.quantile(iters_np, float(q))) for q in ("0.5", "0.9", "0.99", "0.999")},
+        "iteration_histogram": {"<=8": int((iters_np <= 8).sum()), "9-12": int(((iters_np > 8) & (iters_np <= 12)).sum()),
+                                "13-16": int(((iters_np > 12) & (iters_np <= 16)).sum()), "17-24": int(((iters_np > 16) & (iters_np <= 24)).sum()),
+                                "25-40": int(((iters_np > 24) & (iters_np <= 40)).sum()), "41-80": int(((iters_np > 40) & (iters_np <= 80)).sum()),
+                                ">80": int((iters_np > 80).sum())},
     }
     if stub:
         res["stub"] = "%s: CPU build of the solver header, test infrastructure only" % args.stub
