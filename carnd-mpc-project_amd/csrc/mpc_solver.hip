@@ -419,18 +419,29 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     return MPC_ERR_NO_DEVICE;
   }
   MpcHandle *h = new MpcHandle();
+  /* a failing HIP call from here on must not leak the handle */
+#define MPC_CREATE_CHECK(expr)                                                          \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+      mpc_destroy(h);                                                                   \
+      return MPC_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  /* Launch shape: each workgroup is one wave; the kernel needs all 512 registers, so at most one wave runs
-   * per SIMD (4 per CU), and the 36 KB of staging LDS per wave fit four times into a CU's 160 KB.
+  /* Launch shape: each workgroup is one wave; the fp64 kernel needs 378 registers, so at most one wave runs
+   * per SIMD (4 per CU), and the 36 KB of staging LDS per wave fit four times into a CU's 160 KB (fp32: 256
+   * registers, two waves per SIMD, 20 KB each).
    * MPC_STAGING=0 selects the variant with ordinary loads (for A/B measurements). */
   h->staging = true;
   if (const char *e = getenv("MPC_STAGING")) h->staging = atoi(e) != 0;
   const bool f32 = p->precision == MPC_PRECISION_F32;
   if (const char *e = getenv("MPC_F32_OCC")) h->occ2 = atoi(e) != 1;
   if (f32) {
-    MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-    MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-  } else MPC_HIP_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+  } else MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
   {
     /* LDS-resident kernel: as many instances per workgroup as 160 KB hold (32, 16 or 8); one workgroup per CU */
@@ -451,7 +462,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
       case 8: fn = f32 ? (const void *)mpc_solve_lds_kernel<float, 8> : (const void *)mpc_solve_lds_kernel<double, 8>; break;
       default: break;
     }
-    if (fn) MPC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    if (fn) MPC_CREATE_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
     if (const char *e = getenv("MPC_LDS_MAX_BATCH")) h->lds_max_batch = atoll(e);
   }
   h->io_stride = (max_batch + 63) / 64 * 64;
