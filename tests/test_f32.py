@@ -167,3 +167,46 @@ def test_f32_gpu_plain_batch_and_edges(pkg, golden_dir, waypoints):
     assert r32["status"][5] == 3 and r64["status"][5] == 3
     keep = np.arange(B) != 5
     _check_f32({k: v[..., keep] for k, v in r32.items()}, {k: v[..., keep] for k, v in r64.items()}, "plain batch", B - 1)
+
+
+@pytest.mark.gpu
+def test_f32_full_size_properties_config4_shard(pkg, golden_dir, waypoints):
+    """BASELINE.json configs[4] at the size ONE GPU gets (1 048 576 / 8 = 131 072 instances, fp32, per-instance weights, no
+    trajectories): size-independent properties + a sample against the fp64 oracle, every status accounted for."""
+    import torch
+    dev = torch.device("cuda:0")
+    params = _f32_params(pkg, golden_dir)
+    B = 131072
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=56)
+    w = pkg.scenarios.weight_sweep(B, params, seed=57)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=torch.float32)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        ins = [t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"])]
+        r = mpc.solve_torch(*ins, weights=t(w)); torch.cuda.synchronize()
+        st = mpc.stats()
+        out = r["out"].cpu().numpy().astype(np.float64); status = r["status"].cpu().numpy(); iters = r["iters"].cpu().numpy()
+        r2 = mpc.solve_torch(*ins, weights=t(w)); torch.cuda.synchronize()
+        assert torch.equal(r2["out"], r["out"]) and torch.equal(r2["status"], r["status"])            # deterministic
+        perm = np.random.default_rng(3).permutation(B)
+        rp = mpc.solve_torch(t(b["state"][:, perm]), t(b["coeffs"][:, perm]), t(b["yaw_lo"][perm]), t(b["yaw_hi"][perm]), weights=t(w[:, perm]))
+        torch.cuda.synchronize()
+        assert np.array_equal(rp["out"].cpu().numpy(), r["out"].cpu().numpy()[:, perm])                # instances are independent
+    counts = np.bincount(status, minlength=5)
+    assert counts.sum() == B and (st.n_success, st.n_maxiter, st.n_linesearch) == (int(counts[0]), int(counts[1]), int(counts[2]))
+    assert counts[3] == 0 and counts[4] == 0 and counts[0] >= B - 8, counts        # a handful of 131 072 may stop at the cap / on the noise floor
+    ok = status == 0
+    s0, cf = b["state"].astype(np.float32).astype(np.float64), b["coeffs"].astype(np.float32).astype(np.float64)
+    dt, Lf = params.dt, params.Lf
+    assert np.all(np.abs(out[6]) <= params.max_steering + 1e-6) and np.all(out[7, ok] <= params.max_acceleration + 1e-5)
+    assert np.all(out[7, ok] >= params.max_deceleration - 1e-5)
+    # step-1 state satisfies the model equations (MPC.cpp:142-152) from the fixed initial state, to the fp32 solver's tolerance
+    v0 = s0[3]
+    assert np.max(np.abs(out[0] - v0 * dt)[ok]) < 2e-3 and np.max(np.abs(out[1])[ok]) < 2e-3
+    assert np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)[ok]) < 2e-3
+    assert np.max(np.abs(out[3] - (v0 + out[7] * dt))[ok]) < 2e-3
+    assert np.max(np.abs(out[4] - (cf[0] + np.sin(s0[5]) * v0 * dt))[ok]) < 2e-3
+    idx = [int(i) for i in np.random.default_rng(4).choice(np.where(ok)[0], 128, replace=False)]
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, weights=w)
+    assert (ref["status"] == 0).all()
+    d = np.abs(out[:, idx] - ref["out"])
+    assert d[6].max() <= F32_TOL_STEER and d[7].max() <= F32_TOL_ACCEL and d[:6].max() <= F32_TOL_STATE

@@ -238,6 +238,30 @@ def test_full_size_properties(pkg, golden_dir, waypoints, torch_dev):
     assert_parity(out[:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "65536 sample")
 
 
+def test_full_size_properties_config3_shard(pkg, golden_dir, waypoints, torch_dev):
+    """BASELINE.json configs[3] at the size ONE GPU gets (262 144 / 8 = 32 768 instances, N = 25, dt = 0.05, fp64):
+    properties + a sample against the oracle, every status asserted."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
+    B = 32768
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=61)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+        st = mpc.stats()
+        r_again = gpu_solve(pkg, params, b, torch_dev, mpc=mpc)
+    assert st.n_success == B and (r["status"] == 0).all()
+    assert np.array_equal(r_again["out"], r["out"]) and np.array_equal(r_again["traj"], r["traj"])
+    out, s0, cf = r["out"], b["state"], b["coeffs"]
+    dt, Lf, v0 = params.dt, params.Lf, b["state"][3]
+    assert np.all(out[2] >= b["yaw_lo"] - 1e-9) and np.all(out[2] <= b["yaw_hi"] + 1e-9) and np.all(np.abs(out[6]) <= params.max_steering + 1e-9)
+    assert np.max(np.abs(out[0] - v0 * dt)) < 1e-8 and np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-8
+    assert np.max(np.abs(out[3] - (v0 + out[7] * dt))) < 1e-8 and np.max(np.abs(out[4] - (cf[0] + np.sin(s0[5]) * v0 * dt))) < 1e-8
+    assert np.max(np.abs(r["traj"][1] - out[0])) == 0 and r["traj"].shape == (50, B)
+    idx = [int(i) for i in np.random.default_rng(5).choice(B, 48, replace=False)]
+    ref = oracle_solve_batch(O.load_config("config-stable.json", N=25, dt=0.05), b, idx)
+    assert (ref["status"] == 0).all()
+    assert_parity(out[:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "configs[3] shard sample")
+
+
 def test_host_and_device_entry_points_agree(pkg, golden_dir, waypoints, torch_dev):
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
     B = 333
