@@ -1491,8 +1491,12 @@ struct Solver {
       cur = 1 - cur;
       E = T;
       /* fp32: the outputs must have been still for two steps in a row (steps are noisy and can be short for other reasons) */
-      out_step = sizeof(R) == 4 ? mpc_max(alpha * T.du0, out_prev) : alpha * T.du0;
-      out_prev = alpha * T.du0;
+      /* what the polish watches: the step of the outputs (delta_0, a_0), and 0.03 x the largest step of any primal variable
+       * -- the predicted trajectory, whose far end is the least determined part of the solution, has then moved by less than
+       * out_step_tol / 0.03 = 1e-5 m */
+      const R ostep = mpc_max(alpha * T.du0, R(0.03) * alpha * dxinf);
+      out_step = sizeof(R) == 4 ? mpc_max(ostep, out_prev) : ostep;
+      out_prev = ostep;
       ++iter;
       phase = PH_DIR;
       return MPC_RUNNING;

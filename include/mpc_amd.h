@@ -103,7 +103,8 @@ typedef struct MpcParams {
    * interior a0: the frozen tape has no a^2 term -- then still moves by up to ~1e-4 per Newton step, so two correct
    * solvers that stop one iterate apart differ by that much.  With polish != 0 an instance is converged when
    * E_0 <= tol AND the barrier parameter has reached its floor (tol/10) AND the last accepted step moved
-   * (delta0, a0) by at most out_step_tol: the returned point is then the central-path point IPOPT is converging
+   * (delta0, a0) by at most out_step_tol and every primal variable (the predicted trajectory, whose far end is the
+   * least determined part) by at most out_step_tol / 0.03 = 1e-5: the returned point is then the central-path point IPOPT is converging
    * to, reproducible to ~1e-7 whatever the linear algebra (and a barrier parameter within 3x of the floor goes
    * to the floor directly).  Cost: +0.4 iterations per solve.  polish = 0 is IPOPT's own stopping rule. */
   double out_step_tol;       /* default 3e-7 (rad, m/s^2): leaves delta0 within 7e-8 and a0 within 2e-8 of the limit point */

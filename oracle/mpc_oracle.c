@@ -913,7 +913,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     if (!accepted) { status = ORC_RESTORATION_FAILURE; break; }
     if (!ftype && flt->n < 256) { flt->th[flt->n] = (1 - gamma_theta) * theta_k; flt->ph[flt->n] = phi_k - gamma_phi * theta_k; flt->n++; }
     memcpy(x, xt, szn);
-    out_step = alpha * fmax(fabs(dx[P->I.delta]), fabs(dx[P->I.a]));
+    out_step = alpha * fmax(fmax(fabs(dx[P->I.delta]), fabs(dx[P->I.a])), 0.03 * dxn);   /* outputs, and 0.03 x any primal variable (trajectory: 1e-5 m) */
     for (int j = 0; j < m; j++) lam[j] += alpha * dlam[j];
     for (int i = 0; i < n; i++) {
       if (hl[i]) {

@@ -87,7 +87,7 @@ typedef struct OrcSolveOptions {
   /* Termination polish (default 1): IPOPT returns the FIRST iterate with E_0 <= tol; an output the objective
    * determines only weakly (an interior a0: no a^2 term on the frozen tape) still moves ~1e-4 per Newton step
    * there.  With polish the solve ends when E_0 <= tol, mu has reached its floor tol/10 and the last accepted
-   * step moved (delta0, a0) by <= out_step_tol: the central-path point IPOPT converges to, which any correct
+   * step moved (delta0, a0) by <= out_step_tol and any primal variable by <= out_step_tol / 0.03: the central-path point IPOPT converges to, which any correct
    * implementation reproduces to ~1e-7 (a barrier parameter within 3x of the floor goes to the floor directly).  polish = 0 is IPOPT's own stopping rule.  (Same rule, same constants
    * as MpcParams.polish / out_step_tol of include/mpc_amd.h.) */
   int polish;

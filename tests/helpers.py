@@ -35,7 +35,7 @@ TEST_CPP_COMMENTED = [
 # iteration cap strikes.  index -> (status, iterations) that oracle and device solver BOTH report, with the same point:
 OFF_PATH_BATCH = dict(config="config-fast.json", B=16384, seed=45)
 OFF_PATH_INSTANCES = {235: (2, 47), 2080: (2, 43), 11515: (2, 8), 12533: (1, 376),          # restoration stand-in fails / cap
-                      1340: (0, 197), 8676: (0, 128), 9386: (0, 123), 9966: (0, 109), 10296: (0, 104)}   # converge after >100 iterations
+                      1340: (0, 198), 8676: (0, 129), 9386: (0, 124), 9966: (0, 110), 10296: (0, 105)}   # converge after >100 iterations
 # 6049 (cte0 = -1143 m) converges in both solvers, to DIFFERENT local minima (delta0 -0.436 vs +0.042): not a parity case.
 
 # stated fp64 tolerances (SURVEY.md section 8d / BASELINE.md section 4)

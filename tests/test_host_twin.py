@@ -55,20 +55,22 @@ def test_twin_long_horizon(pkg, host_twin, golden_dir, waypoints):
 def test_termination_polish_pins_weakly_determined_outputs(pkg, host_twin, golden_dir, waypoints):
     """IPOPT's stopping rule (polish = 0) leaves an interior a0 up to ~1e-4 from the limit point: shown here by
     solving the same instances at two tolerances.  With the polish the answers agree to the stated 1e-6 whatever
-    iterate crossed the tolerance first, at a cost of less than one iteration per solve."""
+    iterate crossed the tolerance first -- and so do the far ends of the predicted trajectories (1e-5 m), which move by up
+    to 1e-4 m under IPOPT's rule -- at a cost of less than one iteration per solve."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
     b = pkg.scenarios.lake_track_batch(2048, params, waypoints, seed=42)
     exact = params.copy(); exact.out_step_tol = 1e-14                  # polish to the limit point (6 extra steps at most)
-    re_ = twin_solve(host_twin, exact, b, want_traj=False)
+    re_ = twin_solve(host_twin, exact, b)
     plain = params.copy(); plain.polish = 0
-    rp = twin_solve(host_twin, plain, b, want_traj=False)
-    r = twin_solve(host_twin, params, b, want_traj=False)
+    rp = twin_solve(host_twin, plain, b)
+    r = twin_solve(host_twin, params, b)
     ok = (re_["status"] == 0) & (rp["status"] == 0) & (r["status"] == 0)
-    assert ok.sum() >= 2045
+    assert ok.sum() >= 2040            # polishing to 1e-14 sits on the rounding floor: a few line searches give up there
     assert np.max(np.abs(rp["out"][7] - re_["out"][7])[ok]) > 1e-5      # the slack the polish removes
     assert np.max(np.abs(r["out"][7] - re_["out"][7])[ok]) < 1e-7
     assert np.max(np.abs(r["out"][6] - re_["out"][6])[ok]) < 1e-7
-    assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.6
+    assert np.max(np.abs(rp["traj"] - re_["traj"])[:, ok]) > 5e-5 and np.max(np.abs(r["traj"] - re_["traj"])[:, ok]) < 5e-6
+    assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.9          # N = 25; 0.43 on the N = 10 headline workload
 
 
 def test_instances_that_leave_the_central_path(pkg, host_twin, golden_dir, waypoints):
