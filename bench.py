@@ -13,8 +13,9 @@ instances (different PRNG streams), and every batch's per-instance results are g
 all_gather_into_tensor (RCCL) inside the timed region.  Rank 0 prints ONE JSON line.
 
 Other BASELINE.json configurations through flags (same kernels, parity-tested in tests/):
-    configs[3]  --N 25 --dt 0.05 --config config-stable.json --scaling strong --global-batch 262144
-    configs[4]  --weights-sweep --precision f32 --no-traj --scaling strong --global-batch 1048576
+    configs[3]  --N 25 --dt 0.05 --config config-stable.json --scaling strong --global-batch 262144 --inflight 4
+    configs[4]  --weights-sweep --precision f32 --no-traj --scaling strong --global-batch 1048576 --inflight 8
+(heavy-tailed iteration counts: a launch lasts as long as its slowest instance, so more batches in flight pay there)
 
 Steps are pipelined the way a serving loop would run them: `--inflight` (default 2) handles on separate streams,
 so the next batch's waves take the SIMDs that the previous launch frees in its tail, and the gather of batch i
@@ -165,6 +166,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # HIP serves 4 hardware queues per process by default; more batches in flight than that need more (read at HIP start-up)
+    if args.inflight > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.inflight, 8)))
 
     import numpy as np
     import torch
@@ -336,6 +340,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
                    "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch" % world,
                    "collective_mode": pg.mode, "gather_checked": gather_ok, "batches_in_flight": nfl,
+                   "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
                    "termination_polish": bool(params.polish),
                    # the generator redraws instances the reference's own road model does not hold for (scenarios.py)
