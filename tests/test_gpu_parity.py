@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from helpers import TEST_CPP, assert_parity, load_golden, oracle_solve_batch
+from helpers import TEST_CPP, assert_parity, load_golden, oracle_solve_batch, twin_solve
 
 pytestmark = pytest.mark.gpu
 
@@ -185,7 +185,7 @@ def test_scipy_goldens_long_horizon_and_weights(pkg, golden_dir, torch_dev):
         assert np.max(np.abs(r["out"][:6] - ref[:6])) < 5e-5
 
 
-def test_full_size_properties(pkg, golden_dir, waypoints, torch_dev):
+def test_full_size_properties(pkg, host_twin, golden_dir, waypoints, torch_dev):
     """BASELINE.json configs[2] at FULL size (65 536 lake-track states, config-fast.json): size-independent
     properties + a random sample against the oracle."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
@@ -231,6 +231,12 @@ def test_full_size_properties(pkg, golden_dir, waypoints, torch_dev):
     rm = gpu_solve(pkg, params, bm, torch_dev)
     assert (rm["status"] == 0).all()
     assert np.max(np.abs(rm["out"][6] + out[6, :m])) < 1e-6 and np.max(np.abs(rm["out"][7] - out[7, :m])) < 1e-6
+    # EVERY instance against the CPU build of the same solver header (which the CPU tests pin to the oracle at ~1e-10):
+    # the device's own reciprocal / sincos / atan / log and its fused multiply-adds are the only difference
+    tw = twin_solve(host_twin, params, b)
+    assert (tw["status"] == 0).all()
+    assert_parity(out, tw["out"], r["traj"], tw["traj"], "65536 vs CPU build")
+    assert np.abs(r["iters"].astype(int) - tw["iters"]).max() <= 2 and (r["iters"] == tw["iters"]).mean() > 0.95
     # random sample against the oracle
     idx = np.random.default_rng(2).choice(B, 256, replace=False)
     ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx)
