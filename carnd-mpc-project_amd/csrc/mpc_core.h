@@ -1368,6 +1368,8 @@ struct Solver {
    * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
   MPC_HD int line_search_failed() const {
     if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
+    /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
+    if (n_polish > 0 && kkt_error(E, R(0.0)) <= tol) return MPC_STATUS_SUCCESS;
     return MPC_STATUS_LINESEARCH;
   }
 
@@ -1483,9 +1485,15 @@ struct Solver {
         ftype = sw && armijo; /* the filter is augmented unless both hold (W&B step A-7) */
       }
     }
-    /* fp32: a polish step that throws the point out of the acceptable band (a slack of a few ulp collapsing) is not taken
-     * at that length: the line search shortens it, and if no length works the converged iterate is returned as it is */
-    if (accepted && sizeof(R) == 4 && n_polish > 0 && !tiny && !(kkt_error(T, R(0.0)) <= R(10.0) * tol)) accepted = false;
+    /* A polish step must not cost what has been reached.  fp64: a step that leaves tol is DROPPED and the converged iterate
+     * returned (the oracle does the same).  fp32: a step that throws the point out of the acceptable band (a slack of a few
+     * ulp collapsing) is not taken at that length: the line search shortens it, and if no length works the converged iterate
+     * is returned as it is (line_search_failed). */
+    if (accepted && n_polish > 0 && !tiny) {
+      const R Et = kkt_error(T, R(0.0));
+      if (sizeof(R) == 8) { if (!(Et <= tol)) return MPC_STATUS_SUCCESS; }
+      else if (!(Et <= R(10.0) * tol)) accepted = false;
+    }
     if (accepted) {
       if (!ftype) filter_add((R(1.0) - IC::gamma_theta) * theta_k, phi_k - IC::gamma_phi * theta_k);
       cur = 1 - cur;

@@ -731,6 +731,8 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   double *sol = (double *)malloc(sizeof(double) * nk), *dx = sol, *dlam = sol + n;
   double *dzl = (double *)malloc(szn), *dzu = (double *)malloc(szn), *xt = (double *)malloc(szn), *ct = (double *)malloc(szm);
   char *hl = (char *)malloc(n), *hu = (char *)malloc(n);
+  double *x_keep = (double *)malloc(szn), *lam_keep = (double *)malloc(szm), *zl_keep = (double *)malloc(szn), *zu_keep = (double *)malloc(szn);
+  OrcSolveInfo info_keep; memset(&info_keep, 0, sizeof(info_keep));
   Ldl F; F.n = nk; F.M = K; F.perm = (int *)malloc(sizeof(int) * nk); F.blk = (char *)malloc(nk);
   Filter *flt = (Filter *)malloc(sizeof(Filter));
   int nb = 0, status = ORC_MAXITER_EXCEEDED;
@@ -809,6 +811,11 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     info->dual_inf = dinf / df; info->compl_inf = COMPL(0.0) / df; info->iterations = iter;
     if (opt->verbose) fprintf(stderr, "it %3d f=%.10g theta=%.3e dinf=%.3e compl=%.3e mu=%.2e E0=%.3e\n", iter, f, cinf, dinf, COMPL(0.0), mu, E0);
     if (!(E0 == E0)) { status = ORC_NUMERIC_ERROR; break; }
+    if (n_polish > 0 && !(E0 <= opt->tol)) {
+      /* a polish step must not cost what has been reached: one that leaves tol is dropped, the converged iterate returned */
+      memcpy(x, x_keep, szn); memcpy(lam, lam_keep, szm); memcpy(zl, zl_keep, szn); memcpy(zu, zu_keep, szn);
+      *info = info_keep; status = ORC_SUCCESS; break;
+    }
     if (E0 <= opt->tol) {
       /* IPOPT stops at the first iterate with E_0 <= tol.  Termination polish (OrcSolveOptions.polish, see
        * mpc_oracle.h): Newton steps at the final barrier parameter until the outputs have stopped moving. */
@@ -910,8 +917,15 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
       alpha *= 0.5; info->n_backtracks++;
       if (alpha < amin) break;
     }
-    if (!accepted) { status = ORC_RESTORATION_FAILURE; break; }
+    if (!accepted) {
+      /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
+      status = (n_polish > 0 && E0 <= opt->tol) ? ORC_SUCCESS : ORC_RESTORATION_FAILURE;
+      break;
+    }
     if (!ftype && flt->n < 256) { flt->th[flt->n] = (1 - gamma_theta) * theta_k; flt->ph[flt->n] = phi_k - gamma_phi * theta_k; flt->n++; }
+    if (n_polish > 0) {   /* keep the converged iterate: the step about to be taken is a polish step */
+      memcpy(x_keep, x, szn); memcpy(lam_keep, lam, szm); memcpy(zl_keep, zl, szn); memcpy(zu_keep, zu, szn); info_keep = *info;
+    }
     memcpy(x, xt, szn);
     out_step = alpha * fmax(fmax(fabs(dx[P->I.delta]), fabs(dx[P->I.a])), 0.03 * dxn);   /* outputs, and 0.03 x any primal variable (trajectory: 1e-5 m) */
     for (int j = 0; j < m; j++) lam[j] += alpha * dlam[j];
@@ -934,6 +948,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   if (lam_out) memcpy(lam_out, lam, szm);
   free(lam); free(zl); free(zu); free(g); free(c); free(J); free(W); free(K); free(rhs); free(sol);
   free(dzl); free(dzu); free(xt); free(ct); free(hl); free(hu); free(F.perm); free(F.blk); free(flt);
+  free(x_keep); free(lam_keep); free(zl_keep); free(zu_keep);
   return status;
 }
 

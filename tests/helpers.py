@@ -38,6 +38,17 @@ OFF_PATH_INSTANCES = {235: (2, 47), 2080: (2, 43), 11515: (2, 8), 12533: (1, 376
                       1340: (0, 198), 8676: (0, 129), 9386: (0, 124), 9966: (0, 110), 10296: (0, 105)}   # converge after >100 iterations
 # 6049 (cte0 = -1143 m) converges in both solvers, to DIFFERENT local minima (delta0 -0.436 vs +0.042): not a parity case.
 
+# The same at the long horizon: configs[3]'s full batch (262 144 lake-track instances, N = 25, dt = 0.05, PRNG stream 3) has
+# four instances on which the line search runs out of step length in BOTH solvers (same iteration, same point), and one
+# (the last row) that sits on the rounding floor of the tolerance: it converges, and only the polish could still lose it.
+OFF_PATH_N25 = dict(config="config-stable.json", N=25, dt=0.05, expect=[(2, 69), (2, 72), (2, 55), (2, 48), (0, None)], rows=np.array([
+    [0.0, 0.0, 0.0, 42.037103799678775, -0.7602803429124025, 0.10866518072779344, -0.7602803429124025, -0.10909492116528459, 0.011820842324803153, -0.0018921443497710185, 0.0, -1.2926142189803314, 0.1],
+    [0.0, 0.0, 0.0, 39.67702028664985, -0.4886522467329021, 0.10626125436148554, -0.4886522467329021, -0.10666301708143032, 0.01213399309381295, -0.0018268937770139536, 0.0, -1.2766359600284345, 0.1],
+    [0.0, 0.0, 0.0, 39.036764543866774, 0.3456441543053598, 0.12874741007748614, 0.3456441543053598, -0.12946352643669048, 0.015420947915147526, -0.001961261791901044, 0.0, -1.2506188534670613, 0.1],
+    [0.0, 0.0, 0.0, 51.24670367204065, -1.026025721766231, 0.0933026209449351, -1.026025721766231, -0.09357431194811669, 0.0038347925967602116, -0.001994599149009969, 0.0, -1.418708227207186, 0.1],
+    [0.0, 0.0, 0.0, 52.82001239973368, -0.7920241929084179, -0.035491291798923075, -0.7920241929084179, 0.035506201297674365, 0.005042799086039826, 5.937535751267709e-05, 0.0, -0.1, 0.8422130108717072],
+]))   # columns: state[6], coeffs[5], yaw_lo, yaw_hi
+
 # stated fp64 tolerances (SURVEY.md section 8d / BASELINE.md section 4)
 TOL_STEER = 1e-6   # rad, delta0
 TOL_ACCEL = 1e-6   # m/s^2, a0

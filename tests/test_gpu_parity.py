@@ -153,6 +153,19 @@ def test_instances_that_leave_the_central_path(pkg, golden_dir, waypoints, torch
         assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, j])) < (1e-6 if want_status == 0 else 1e-4), i
 
 
+def test_long_horizon_instances_that_leave_the_central_path(pkg, golden_dir, torch_dev):
+    """helpers.OFF_PATH_N25 on the device (the failing 4 of configs[3]'s 262 144 instances, and the one on the rounding floor)."""
+    from helpers import OFF_PATH_N25 as T
+    params = pkg.params_from_json(os.path.join(golden_dir, T["config"]), N=T["N"], dt=T["dt"])
+    rows = T["rows"]
+    b = {"state": rows[:, :6].T.copy(), "coeffs": rows[:, 6:11].T.copy(), "yaw_lo": rows[:, 11].copy(), "yaw_hi": rows[:, 12].copy()}
+    r = gpu_solve(pkg, params, b, torch_dev, want_traj=False)
+    ref = oracle_solve_batch(O.load_config(T["config"], N=T["N"], dt=T["dt"]), b, range(len(rows)), opt=O.default_options(max_iter=params.max_iter))
+    for i, (st, it) in enumerate(T["expect"]):
+        assert r["status"][i] == st == ref["status"][i], (i, r["status"][i], ref["status"][i])
+        assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, i])) < (1e-6 if st == 0 else 1e-4), i
+
+
 def test_scipy_goldens(pkg, golden_dir, torch_dev):
     gold = load_golden("scipy_cross_solve.json")
     for cfgname in ("config-stable.json", "config-fast.json"):

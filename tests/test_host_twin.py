@@ -93,6 +93,22 @@ def test_instances_that_leave_the_central_path(pkg, host_twin, golden_dir, waypo
         assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, j])) < 1e-6, i
 
 
+def test_long_horizon_instances_that_leave_the_central_path(pkg, host_twin, golden_dir):
+    """helpers.OFF_PATH_N25: the 4 of 262 144 N = 25 instances that end in LINESEARCH, identically in oracle and device solver,
+    and the one on the rounding floor of tol, which both report as converged at the same point."""
+    from helpers import OFF_PATH_N25 as T
+    params = pkg.params_from_json(os.path.join(golden_dir, T["config"]), N=T["N"], dt=T["dt"])
+    rows = T["rows"]
+    b = {"state": rows[:, :6].T.copy(), "coeffs": rows[:, 6:11].T.copy(), "yaw_lo": rows[:, 11].copy(), "yaw_hi": rows[:, 12].copy()}
+    r = twin_solve(host_twin, params, b, want_traj=False)
+    ref = oracle_solve_batch(O.load_config(T["config"], N=T["N"], dt=T["dt"]), b, range(len(rows)), opt=O.default_options(max_iter=params.max_iter))
+    for i, (st, it) in enumerate(T["expect"]):
+        assert r["status"][i] == st and ref["status"][i] == st, (i, r["status"][i], ref["status"][i])
+        if it is not None:
+            assert r["iters"][i] == it and ref["iters"][i] == it
+        assert np.max(np.abs(r["out"][:8, i] - ref["out"][:8, i])) < 1e-6
+
+
 def test_twin_weight_sweep_with_zero_velocity_weight(pkg, host_twin, golden_dir, waypoints):
     """SURVEY.md section 8d, Config 5: the sweep including velocity weight 0 (the acceleration is then bang-bang between
     maxDeceleration and maxAcceleration, examples/velocity-weights.png): fp64 agrees with the oracle to the stated 1e-6."""
