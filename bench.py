@@ -70,7 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-process path on a single GPU or with --stub)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (handles on separate streams)")
+    ap.add_argument("--inflight", type=int, default=0, help="batches in flight per GPU (handles on separate streams); default: 2 in fp64, "
+                    "4 in fp32 (measured best for each)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     ap.add_argument("--force-collective", action="store_true", help="one rank only: initialise RCCL with world size 1 and run the per-batch "
@@ -78,7 +79,10 @@ def parse_args(argv=None):
     ap.add_argument("--stub", default="", help="TEST ONLY (tests/test_bench_spawn.py): 'host_twin' replaces the device solve by "
                     "the CPU build of the solver header so that the multi-process plumbing can be exercised without a GPU; "
                     "the line it prints is marked as a stub and is not a measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.inflight <= 0:
+        args.inflight = 4 if args.precision == "f32" else 2
+    return args
 
 
 def spawn_ranks(args):
