@@ -104,3 +104,38 @@ def test_replay_tool_matches_oracle_handler(pkg, golden_dir, waypoints):
                 assert abs(d["steering_angle"] - ref_steer) * params.max_steering < 5 * TOL_STEER
                 assert abs(d["throttle"] - ref_thr) < 1e-5
             prev[i] = d["throttle"]
+
+
+@pytest.mark.gpu
+def test_replay_tool_over_tcp(pkg, golden_dir, waypoints):
+    """The same replay over one TCP connection (newline-delimited frames on 127.0.0.1): replies come back on the socket and
+    are byte-identical to the stdin/stdout mode's."""
+    import socket
+    import time
+    cfgname = "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    B = 8
+    f1, _, _ = _frames_for(pkg, params, waypoints, B, 73)
+    text = "\n".join(f1 + ['42["telemetry",null]'] + f1[:B - 1]) + "\n"
+    exe = os.path.join(os.path.dirname(pkg.library_path()), "mpc_replay")
+    cfg = os.path.join(golden_dir, cfgname)
+    ref = subprocess.run([exe, cfg, "--cars", str(B)], input=text, capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr
+    s0 = socket.socket(); s0.bind(("127.0.0.1", 0)); port = s0.getsockname()[1]; s0.close()
+    p = subprocess.Popen([exe, cfg, "--cars", str(B), "--tcp", str(port)], stderr=subprocess.PIPE, text=True)
+    try:
+        assert "listening" in p.stderr.readline()
+        c = socket.create_connection(("127.0.0.1", port), timeout=60)
+        c.sendall(text.encode()); c.shutdown(socket.SHUT_WR)
+        got = b""
+        while True:
+            chunk = c.recv(65536)
+            if not chunk:
+                break
+            got += chunk
+        c.close()
+        assert p.wait(timeout=120) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert got.decode() == ref.stdout and got.count(b"\n") == 2 * B
