@@ -15,7 +15,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as G
-    return G.load_package()
+    p = G.load_package()
+    if not os.path.exists(p.library_path()):      # a fresh checkout: compile the HIP extension first (hipcc cross-compiles without a GPU)
+        p.build_library()
+    return p
 
 
 @pytest.fixture(scope="session")
