@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--inflight", type=int, default=0, help="batches in flight per GPU (handles on separate streams); default: 2 in fp64, "
                     "4 in fp32 (measured best for each)")
+    ap.add_argument("--pass-cuts", default="", help="multi-phase solve (MpcParams.pass_cut, pass_cut_next): up to four comma-separated "
+                    "cuts, e.g. 16,16,32 -- instances still running after that many passes are re-packed into dense waves for "
+                    "a further launch; bitwise the same results; made for heavy-tailed batches (weight sweeps, long horizons)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     ap.add_argument("--force-collective", action="store_true", help="one rank only: initialise RCCL with world size 1 and run the per-batch "
@@ -218,6 +221,11 @@ def main():
     f32 = args.precision == "f32"
     if f32:
         params.precision = pkg.PRECISION_F32
+    cuts = [int(c) for c in args.pass_cuts.split(",") if c.strip()][:4]
+    if cuts:
+        params.pass_cut = cuts[0]
+        for k, c in enumerate(cuts[1:]):
+            params.pass_cut_next[k] = c
     tdt = torch.float32 if f32 else torch.float64
     wp = pkg.scenarios.load_waypoints(os.path.join(golden, "lake_track_waypoints.csv"))
     if args.scaling == "strong":
@@ -346,7 +354,7 @@ def main():
                    "collective_mode": pg.mode, "gather_checked": gather_ok, "batches_in_flight": nfl,
                    "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
-                   "termination_polish": bool(params.polish),
+                   "termination_polish": bool(params.polish), "pass_cuts": cuts,
                    # the generator redraws instances the reference's own road model does not hold for (scenarios.py)
                    "instance_filter": ("none (unfiltered draws)" if args.unfiltered else
                                        "rejection sampling, %d draws for %d instances" % (batch["drawn"], B)),

@@ -39,7 +39,7 @@ class MpcParams(C.Structure):
         ("ipopt_timeout", C.c_double), ("branch_mode", C.c_int32), ("precision", C.c_int32),
         ("max_iter", C.c_int32), ("pass_cut", C.c_int32), ("tol", C.c_double),
         ("out_step_tol", C.c_double), ("tol_f32", C.c_double), ("polish", C.c_int32),
-        ("reserved_i", C.c_int32 * 3), ("reserved_d", C.c_double * 2),
+        ("pass_cut_next", C.c_int32 * 3), ("reserved_d", C.c_double * 2),
     ]
 
     def copy(self):

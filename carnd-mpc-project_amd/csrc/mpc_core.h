@@ -1305,7 +1305,7 @@ struct Solver {
   int phase, iter, n_polish;
   bool ls_start, tiny;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
-  R out_prev;
+  R out_prev;     /* the same of the step before (fp32 wants two quiet steps in a row) */
   R tol, out_tol;  /* "tol" of this precision (MpcParams.tol or tol_f32) and the polish's step tolerance */
   R alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
   R theta_k, phi_k, pth, pdp, amin;   /* line-search state */
@@ -1339,7 +1339,7 @@ struct Solver {
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
     a(22) = (R)nf; a(23) = (R)iter; a(24) = (R)n_reg; a(25) = (R)cur; a(26) = E.ok ? R(1.0) : R(0.0);
     a(27) = ls_start ? R(1.0) : R(0.0); a(28) = (R)attempt; a(29) = (R)it_total;
-    a(30) = out_step; a(31) = (R)n_polish; a(32) = R(0.0); a(33) = R(0.0); a(34) = R(0.0); a(35) = R(0.0);
+    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(33) = R(0.0); a(34) = R(0.0); a(35) = R(0.0);
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
     begin(a(27) != R(0.0));
@@ -1347,7 +1347,7 @@ struct Solver {
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
     nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != R(0.0);
-    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31);
+    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32);
     iters = iter; phase = PH_DIR;
   }
 
@@ -1356,7 +1356,7 @@ struct Solver {
     /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
-    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = IC::huge;
+    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = out_prev = IC::huge;
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
     theta_max = theta_min = dw_last = R(0.0);
     theta_k = phi_k = pth = pdp = amin = R(0.0);

@@ -53,6 +53,9 @@ struct DeviceGuard {
 
 constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchronise */
 constexpr int64_t kLdsPerCu = 160 * 1024;
+constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
+constexpr int kCounterInts = 16;    /* two counters per phase */
+constexpr int kParkRows = 36;       /* Solver::PARK_N */
 
 /*
  * One instance per lane.  Inputs/outputs are [quantity][instance] so that a wave's access to one
@@ -75,25 +78,33 @@ template <class R> constexpr size_t staging_lds_bytes() { return 2u * mpc::Field
  * is a per-lane state machine (Solver::step), so the lanes of a wave may be on different instances in different
  * phases.  With a grid of ceil(B/64) waves this is the plain one-instance-per-lane launch.
  *
- * Two-phase solve (MpcTwoPhase): a wave lasts as long as its slowest instance, and two thirds of the instances are
- * done after ~10 iterations while the slowest need 25.  Phase A therefore PARKS an instance that is still running
- * after `pass_cut` passes (at a pass boundary in the DIR phase: 36 scalars + its current iterate, which stays where
- * it is) and appends it to a list; phase B, launched right behind on the same stream, is the same kernel taking its
- * work from that list: a lane copies the parked iterate into its own tile, restores the scalars and carries on.  The
- * arithmetic of an instance does not change (results are bitwise identical), but the unfinished third is re-packed
- * into dense waves: ~19 % fewer wave passes, and as much less workspace traffic.
+ * Multi-phase solve (MpcPhase): a wave lasts as long as its slowest instance, and two thirds of the instances are
+ * done after ~10 iterations while the slowest need 25 (headline workload) or 100-200 (weight sweeps, long horizons).
+ * A phase with a cut therefore PARKS an instance that is still running after `pass_cut` passes (at a pass boundary
+ * in the DIR phase: 36 scalars + its current iterate, which stays where it is) and appends it to a list; the next
+ * phase, launched right behind on the same stream, is the same kernel taking its work from that list: a lane copies
+ * the parked iterate into its own tile, restores the scalars and carries on -- and may park it again if that phase
+ * has a cut too.  The arithmetic of an instance does not change (results are bitwise identical), but the unfinished
+ * part is re-packed into dense waves after every cut, so a wave slot is not held by one or two stragglers.  Lists,
+ * scalars and workspaces alternate between two buffers (phase p reads what phase p-1 wrote).
  *
  * Exit: a lane stops asking once its counter has passed the end; the wave leaves when no lane holds an instance and
- * none can get one -- every pass either advances an instance (bounded by max_iter) or consumes the counter. */
-struct MpcTwoPhase {
-  int32_t *ctl;            /* [0] fresh counter, [1] number of parked instances, [2] resume counter */
-  int32_t *list_inst;      /* parked: instance index */
-  int32_t *list_src;       /* parked: wave * 64 + lane of the tile column that holds its iterate */
-  double *park;            /* [PARK_N][ld_park] solver scalars, column = position in the list */
+ * none can get one -- every pass either advances an instance (bounded by max_iter and the cut) or consumes the
+ * counter.  A lane that has parked takes nothing else (its column keeps the iterate), so a phase with a cut needs as
+ * many lanes as it may receive instances: the host launches every phase with the grid of the first. */
+struct MpcPhase {
+  int32_t *take;            /* counter this phase takes its work from */
+  const int32_t *n_in;      /* resume: number of parked instances to take (written by the previous phase) */
+  int32_t *n_out;           /* number of instances this phase has parked */
+  const int32_t *in_inst;   /* resume: instance index ... */
+  const int32_t *in_src;    /* ... and wave * 64 + lane of the tile column (of src_ws) that holds its iterate */
+  const double *in_park;    /* resume: [PARK_N][ld_park] solver scalars, column = position in the list */
+  int32_t *out_inst, *out_src;
+  double *out_park;
   int64_t ld_park;
-  const void *src_ws;      /* phase B: workspace of phase A */
-  int32_t pass_cut;        /* phase A: park after this many passes (0 = never) */
-  int32_t resume;          /* 1 = phase B */
+  const void *src_ws;       /* resume: workspace of the previous phase */
+  int32_t pass_cut;         /* park after this many passes in this phase (0 = never) */
+  int32_t resume;           /* 0 = first phase (fresh instances), 1 = takes parked ones */
   /* Hand-over policy.  Writing a finished instance out and fetching the next one (set-up, start point: 270 stores) is
    * divergent code that the whole wave pays for, ~4 us per event against ~80 us per pass, and with 64 lanes finishing at
    * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
@@ -109,11 +120,12 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
     const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, R *__restrict__ wsbase,
-    const int64_t tile_reals, const MpcTwoPhase T) {
+    const int64_t tile_reals, const MpcPhase T) {
   extern __shared__ double smem[];
   using WS = mpc::TiledWorkspace<STAGING, R>;
   using SV = mpc::Solver<WS, R>;
   using FL = mpc::Fields<R>;
+  static_assert(SV::PARK_N == kParkRows, "park buffer rows");
   WS ws;
   ws.tile = (typename WS::greal *)(wsbase + (int64_t)blockIdx.x * tile_reals);
   ws.lane = threadIdx.x;
@@ -122,9 +134,9 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   int64_t i = 0;
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
   int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0;
-  const int64_t n_work = T.resume ? (int64_t)T.ctl[1] : B;
+  const int64_t n_work = T.resume ? (int64_t)*T.n_in : B;
   for (;;) {
-    /* ---- hand-over point (wave-uniform decision, see MpcTwoPhase) ---- */
+    /* ---- hand-over point (wave-uniform decision, see MpcPhase) ---- */
     const int n_wait = MPC_WAVE_COUNT(fin || (!have && more));
     if (n_wait > 0) {
       if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait) {
@@ -139,10 +151,10 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           fin = false;
         }
         if (!have && more) {
-          const int64_t pos = (int64_t)atomicAdd(T.ctl + (T.resume ? 2 : 0), 1);
+          const int64_t pos = (int64_t)atomicAdd(T.take, 1);
           more = pos < n_work;
           if (more) {
-            i = T.resume ? (int64_t)T.list_inst[pos] : pos;
+            i = T.resume ? (int64_t)T.in_inst[pos] : pos;
             R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
             for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
@@ -158,10 +170,10 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
             const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
             if (T.resume) {
               /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
-              const double *pk = T.park + pos;
+              const double *pk = T.in_park + pos;
               const int64_t lp = T.ld_park;
               S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
-              const int src = T.list_src[pos];
+              const int src = T.in_src[pos];
               WS wsrc = ws;
               wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
               wsrc.lane = src & 63;
@@ -192,11 +204,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           S.begin(false);
         } else { fin = true; fin_status = r; have = false; }
       } else if (T.pass_cut > 0 && passes >= T.pass_cut && S.phase == SV::PH_DIR) {
-        /* still running: park it for phase B */
-        const int64_t pos = (int64_t)atomicAdd(T.ctl + 1, 1);
-        T.list_inst[pos] = (int32_t)i;
-        T.list_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
-        double *pk = T.park + pos;
+        /* still running: park it for the next phase */
+        const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
+        T.out_inst[pos] = (int32_t)i;
+        T.out_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+        double *pk = T.out_park + pos;
         const int64_t lp = T.ld_park;
         S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
         have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
@@ -373,17 +385,36 @@ struct MpcHandle {
   int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
-  int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcTwoPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
-  /* two-phase solve: second workspace, parked-instance list and scalars (allocated on first use) */
-  int pass_cut = 0;           /* MpcParams.pass_cut, or MPC_PASS_CUT in the environment (0 = single launch) */
+  int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
+  /* multi-phase solve: second workspace, two parked-instance lists and two sets of scalars (allocated on first use) */
+  int n_cuts = 0;             /* MpcParams.pass_cut + pass_cut_next[], or MPC_PASS_CUT=a,b,c,d in the environment (none = single launch) */
+  int cuts[kMaxCuts] = {0, 0, 0, 0};
   int64_t two_phase_min = 8192;
   void *ws2 = nullptr;
-  double *d_park = nullptr;
-  int32_t *d_list = nullptr;
+  double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
+  int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   /* last call */
   int64_t last_B = 0;
   bool timed = false;
 };
+
+/* the cut schedule of the multi-phase solve: MpcParams.pass_cut, pass_cut_next[0..2] (a zero ends the list), overridden
+ * by MPC_PASS_CUT=a[,b[,c[,d]]] in the environment */
+static void set_cuts(MpcHandle *h, const MpcParams *p) {
+  h->n_cuts = 0;
+  const int32_t given[kMaxCuts] = {p->pass_cut, p->pass_cut_next[0], p->pass_cut_next[1], p->pass_cut_next[2]};
+  for (int q = 0; q < kMaxCuts && given[q] > 0; q++) h->cuts[h->n_cuts++] = given[q];
+  if (const char *e = getenv("MPC_PASS_CUT")) {
+    h->n_cuts = 0;
+    for (const char *c = e; *c && h->n_cuts < kMaxCuts;) {
+      const int v = atoi(c);
+      if (v <= 0) break;
+      h->cuts[h->n_cuts++] = v;
+      while (*c && *c != ',') ++c;
+      if (*c == ',') ++c;
+    }
+  }
+}
 
 static int validate_params(const MpcParams *p) {
   if (!p) return MPC_ERR_INVALID;
@@ -476,11 +507,11 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void **)&h->d_counter, 4 * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_counter, kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-  h->pass_cut = p->pass_cut > 0 ? p->pass_cut : 0;
-  if (const char *e3 = getenv("MPC_PASS_CUT")) { h->pass_cut = atoi(e3); if (h->pass_cut < 0) h->pass_cut = 0; }
+  set_cuts(h, p);
+  if (const char *e3 = getenv("MPC_PHASE_MIN_BATCH")) { h->two_phase_min = atoll(e3); if (h->two_phase_min < 1) h->two_phase_min = 1; }
   if (const char *e4 = getenv("MPC_REFILL_MIN")) { h->refill_min = atoi(e4); if (h->refill_min < 1) h->refill_min = 1; }
   if (const char *e5 = getenv("MPC_REFILL_WAIT")) { h->refill_wait = atoi(e5); if (h->refill_wait < 0) h->refill_wait = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
@@ -494,6 +525,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (rc != MPC_OK) return rc;
   if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
   h->params = *p;
+  set_cuts(h, p);
   return MPC_OK;
 }
 
@@ -575,12 +607,12 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  const bool two = h->pass_cut > 0 && h->inst_per_lane == 1 && B >= h->two_phase_min;
-  if (two && !h->ws2) {
+  const int n_cuts = (h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
+  if (n_cuts > 0 && !h->ws2) {
     const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(R);
     MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 36 * h->io_stride));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 2 * h->io_stride));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
   }
   if (h->lds_lanes > 0 && B <= h->lds_max_batch) {
     MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
@@ -591,14 +623,10 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
     return MPC_OK;
   }
-  MpcTwoPhase T;
-  T.ctl = h->d_counter; T.list_inst = h->d_list; T.list_src = h->d_list ? h->d_list + h->io_stride : nullptr;
-  T.park = h->d_park; T.ld_park = h->io_stride; T.src_ws = h->ws; T.pass_cut = two ? h->pass_cut : 0; T.resume = 0;
-  T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
   int32_t *it_out = iters ? iters : h->d_iters;
-  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(int32_t), s));
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, kCounterInts * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-  auto launch = [&](unsigned grid, void *wsp, const MpcTwoPhase &tp) {
+  auto launch = [&](unsigned grid, void *wsp, const MpcPhase &tp) {
     constexpr int kOcc2 = sizeof(R) == 4 ? 2 : 1;
     if (h->staging && h->occ2)
       hipLaunchKernelGGL((mpc_solve_kernel<true, R, kOcc2>), dim3(grid), dim3(kBlock), staging_lds_bytes<R>(), s, h->params, B, ld, ldo, state, coeffs,
@@ -610,14 +638,27 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
       hipLaunchKernelGGL((mpc_solve_kernel<false, R, 1>), dim3(grid), dim3(kBlock), 0, s, h->params, B, ld, ldo, state, coeffs,
                          yaw_lo, yaw_hi, weights, out, traj, status, it_out, (R *)wsp, h->ws_stride, tp);
   };
-  launch((unsigned)waves, h->ws, T);
-  if (two) {
-    /* phase B: the parked instances, re-packed; its grid covers half the batch, and lanes take further work from the
-     * list if more than that was parked */
+  /* phase p takes from counter [2p], parks into list p & 1 and counts its parked instances in [2p + 1]; phase p > 0
+   * reads list (p - 1) & 1 and the workspace of phase p - 1; every phase has the grid of the first (see MpcPhase) */
+  for (int p = 0; p <= n_cuts; ++p) {
+    MpcPhase T;
+    const int wr = p & 1, rd = wr ^ 1;
+    T.take = h->d_counter + 2 * p;
+    T.n_out = h->d_counter + 2 * p + 1;
+    T.n_in = p > 0 ? h->d_counter + 2 * (p - 1) + 1 : nullptr;
+    T.out_inst = h->d_list ? h->d_list + (int64_t)(2 * wr) * h->io_stride : nullptr;
+    T.out_src = h->d_list ? h->d_list + (int64_t)(2 * wr + 1) * h->io_stride : nullptr;
+    T.in_inst = h->d_list ? h->d_list + (int64_t)(2 * rd) * h->io_stride : nullptr;
+    T.in_src = h->d_list ? h->d_list + (int64_t)(2 * rd + 1) * h->io_stride : nullptr;
+    T.out_park = h->d_park ? h->d_park + (int64_t)wr * kParkRows * h->io_stride : nullptr;
+    T.in_park = h->d_park ? h->d_park + (int64_t)rd * kParkRows * h->io_stride : nullptr;
+    T.ld_park = h->io_stride;
+    T.src_ws = rd ? h->ws2 : h->ws;
+    T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
+    T.resume = p > 0;
+    T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    launch((unsigned)waves, wr ? h->ws2 : h->ws, T);
     MPC_HIP_CHECK(hipGetLastError());
-    MpcTwoPhase T2 = T;
-    T2.resume = 1; T2.pass_cut = 0;
-    launch((unsigned)((waves + 1) / 2), h->ws2, T2);
   }
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));

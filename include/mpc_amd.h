@@ -95,8 +95,9 @@ typedef struct MpcParams {
   int32_t branch_mode;       /* MPC_BRANCH_FROZEN: CppAD tape recorded once at the start point */
   int32_t precision;         /* MPC_PRECISION_F64 (default), or MPC_PRECISION_F32: see mpc_solve_batch_device_f32 */
   int32_t max_iter;          /* IPOPT default 3000; default here 200 */
-  int32_t pass_cut;          /* two-phase solve: park instances still running after this many passes and finish them,
-                              * re-packed, in a second launch (0 = single launch, the default) */
+  int32_t pass_cut;          /* multi-phase solve: park instances still running after this many passes and finish them,
+                              * re-packed into dense waves, in a further launch (0 = single launch, the default; more
+                              * cuts in pass_cut_next; results are bitwise the same) */
   double tol;                /* IPOPT "tol", default 1e-8 */
   /* Termination polish (default on).  IPOPT stops at the FIRST iterate whose scaled optimality error is <= tol
    * (MPC.cpp:290-292 leaves that default untouched).  An output that the objective determines only weakly -- an
@@ -111,7 +112,8 @@ typedef struct MpcParams {
   double tol_f32;            /* "tol" of the MPC_PRECISION_F32 solver, default 5e-4 (barrier floor tol_f32/25, polish step
                               * 0.6 tol_f32; see DESIGN.md, fp32 mode) */
   int32_t polish;            /* default 1 */
-  int32_t reserved_i[3];
+  int32_t pass_cut_next[3];  /* further cuts (passes counted from the previous cut; a zero ends the list), e.g.
+                              * pass_cut 16, next {16, 32, 0}: four launches, made for heavy-tailed batches */
   double reserved_d[2];
 } MpcParams;
 

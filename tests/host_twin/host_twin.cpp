@@ -92,31 +92,34 @@ extern "C" void mpc_host_twin_tel_cmd(const MpcParams *p, const double *o8, doub
   mpc::command_from_run(*p, o8, &cmd2[0], &cmd2[1]);
 }
 
-/* The two-phase solve of the device kernel, replayed on the host: run the state machine, PARK the instance after
+/* The multi-phase solve of the device kernel, replayed on the host: run the state machine, PARK the instance after
  * `pass_cut` passes (at a pass boundary in the DIR phase), then RESUME it in a different solver object on a different
- * workspace that only receives the current iterate slot -- exactly what phase B of mpc_solve_kernel does. */
-extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, const double *state,
-                                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
-                                          const double *weights, double *out, int32_t *status, int32_t *iters,
-                                          int32_t *was_parked) {
+ * workspace that only receives the current iterate slot -- exactly what a resume phase of mpc_solve_kernel does.  With
+ * `repeat` the instance is parked again every `pass_cut` passes (the two objects take turns), as under a cut schedule. */
+template <class R>
+static int solve_parked_t(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, int repeat, const R *state, const R *coeffs,
+                          const R *yaw_lo, const R *yaw_hi, const R *weights, R *out, int32_t *status, int32_t *iters,
+                          int32_t *was_parked) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N, M = N - 1;
-  using SV = mpc::Solver<mpc::HostWorkspace<double>, double>;
-  using FD = mpc::Fields<double>;
-  std::vector<double> wsA((size_t)M * FD::STAGE_SZ), wsB((size_t)M * FD::STAGE_SZ, -7.0);
+  using SV = mpc::Solver<mpc::HostWorkspace<R>, R>;
+  using FD = mpc::Fields<R>;
+  std::vector<R> wsA((size_t)M * FD::STAGE_SZ), wsB((size_t)M * FD::STAGE_SZ, R(-7.0));
   for (int64_t i = 0; i < B; i++) {
-    double st[6], cf[MPC_NCOEF], w[MPC_NW], park[SV::PARK_N];
+    R st[6], cf[MPC_NCOEF], w[MPC_NW];
+    double park[SV::PARK_N];
     for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
     for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
-    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : p->weights[q];
-    SV A(*p, mpc::HostWorkspace<double>{wsA.data()});
+    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)p->weights[q];
+    SV A(*p, mpc::HostWorkspace<R>{wsA.data()});
     int s = A.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0, passes = 0;
     SV *fin = &A;
-    SV Bs(*p, mpc::HostWorkspace<double>{wsB.data()});
+    SV Bs(*p, mpc::HostWorkspace<R>{wsB.data()});
     was_parked[i] = 0;
     if (s == MPC_STATUS_SUCCESS) {
       A.begin(true);
       SV *cur = &A;
+      std::vector<R> *wcur = &wsA, *woth = &wsB;
       for (;;) {
         const int r = cur->step();
         ++passes;
@@ -125,23 +128,42 @@ extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t
           s = r; cur->iters += it_total; fin = cur;
           break;
         }
-        if (cur == &A && pass_cut > 0 && passes >= pass_cut && A.phase == SV::PH_DIR) {
-          A.park([&park](int q) -> double & { return park[q]; }, attempt, it_total);
-          std::fill(wsB.begin(), wsB.end(), -7.0);                      /* nothing but the iterate slot comes along */
-          Bs.setup(st, cf, yaw_lo[i], yaw_hi[i], w, false);
-          Bs.unpark([&park](int q) -> double { return park[q]; }, attempt, it_total);
-          const int I = Bs.cur ? FD::IT1 : FD::IT0;
+        if ((cur == &A || repeat) && pass_cut > 0 && passes >= pass_cut && cur->phase == SV::PH_DIR) {
+          SV *oth = cur == &A ? &Bs : &A;
+          cur->park([&park](int q) -> double & { return park[q]; }, attempt, it_total);
+          std::fill(woth->begin(), woth->end(), R(-7.0));                /* nothing but the iterate slot comes along */
+          oth->setup(st, cf, yaw_lo[i], yaw_hi[i], w, false);
+          oth->unpark([&park](int q) -> double { return park[q]; }, attempt, it_total);
+          const int I = oth->cur ? FD::IT1 : FD::IT0;
           for (int k = 0; k < M; k++)
-            for (int f = 0; f < FD::IT_SZ; f++) wsB[(size_t)k * FD::STAGE_SZ + I + f] = wsA[(size_t)k * FD::STAGE_SZ + I + f];
-          cur = &Bs; was_parked[i] = 1;
+            for (int f = 0; f < FD::IT_SZ; f++) (*woth)[(size_t)k * FD::STAGE_SZ + I + f] = (*wcur)[(size_t)k * FD::STAGE_SZ + I + f];
+          cur = oth; std::swap(wcur, woth); was_parked[i] += 1; passes = 0;
         }
       }
     }
-    double o9[9];
-    double *o = o9;
-    fin->unpack([o](int q) -> double & { return o[q]; }, [o](int) -> double & { return o[0]; }, false);
+    R o9[9];
+    R *o = o9;
+    fin->unpack([o](int q) -> R & { return o[q]; }, [o](int) -> R & { return o[0]; }, false);
     for (int q = 0; q < 9; q++) out[q * ld + i] = o9[q];
     status[i] = s; iters[i] = fin->iters;
   }
   return MPC_OK;
+}
+extern "C" int mpc_host_twin_solve_parked(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, const double *state,
+                                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                          const double *weights, double *out, int32_t *status, int32_t *iters,
+                                          int32_t *was_parked) {
+  return solve_parked_t<double>(p, B, ld, pass_cut, 0, state, coeffs, yaw_lo, yaw_hi, weights, out, status, iters, was_parked);
+}
+extern "C" int mpc_host_twin_solve_reparked(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, const double *state,
+                                            const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                            const double *weights, double *out, int32_t *status, int32_t *iters,
+                                            int32_t *was_parked) {
+  return solve_parked_t<double>(p, B, ld, pass_cut, 1, state, coeffs, yaw_lo, yaw_hi, weights, out, status, iters, was_parked);
+}
+extern "C" int mpc_host_twin_solve_reparked_f32(const MpcParams *p, int64_t B, int64_t ld, int pass_cut, const float *state,
+                                                const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                                                const float *weights, float *out, int32_t *status, int32_t *iters,
+                                                int32_t *was_parked) {
+  return solve_parked_t<float>(p, B, ld, pass_cut, 1, state, coeffs, yaw_lo, yaw_hi, weights, out, status, iters, was_parked);
 }

@@ -397,9 +397,10 @@ def test_lds_resident_kernel_is_bitwise_identical(pkg, golden_dir, waypoints, to
             os.environ["MPC_LDS"] = old
 
 
-def test_two_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
-    """Parking unfinished instances after MPC_PASS_CUT passes and finishing them, re-packed, in a second launch must
-    not change a single bit: the same arithmetic on the same state, only in another lane."""
+def test_multi_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """Parking unfinished instances after a number of passes and finishing them, re-packed, in further launches (up to
+    four cuts, MPC_PASS_CUT=a,b,c,d or MpcParams.pass_cut / pass_cut_next) must not change a single bit: the same
+    arithmetic on the same state, only in another lane."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
     old = os.environ.get("MPC_PASS_CUT")
     try:
@@ -407,13 +408,37 @@ def test_two_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torch_
             q = params.copy(); q.N = N; q.dt = dt
             b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=78)
             res = {}
-            for cut in ("0", "12", "5"):
+            for cut in ("0", "12", "5", "4,4,4,4", "3,9", "16,16,32"):
                 os.environ["MPC_PASS_CUT"] = cut
                 res[cut] = gpu_solve(pkg, q, b, torch_dev)
-            for cut in ("12", "5"):
+            for cut in res:
                 for key in ("out", "traj", "status", "iters"):
                     assert np.array_equal(res[cut][key], res["0"][key]), (N, cut, key)
             assert (res["0"]["status"] == 0).mean() > 0.999 and res["0"]["iters"].max() > 14   # some instances did get parked
+        os.environ.pop("MPC_PASS_CUT", None)
+        # the heavy-tailed case the schedule is made for: per-instance weights, cuts given through MpcParams, both precisions
+        import torch
+        B = 16384
+        b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=79)
+        w = pkg.scenarios.weight_sweep(B, params, seed=80)
+        for prec, dt_ in ((pkg.PRECISION_F64, torch.float64), (pkg.PRECISION_F32, torch.float32)):
+            res = {}
+            for cuts in ((0, 0, 0, 0), (16, 16, 32, 0), (8, 8, 8, 8)):
+                q = params.copy(); q.precision = prec
+                q.pass_cut = cuts[0]
+                for k in range(3):
+                    q.pass_cut_next[k] = cuts[1 + k]
+                t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=dt_)
+                with pkg.BatchedMPC(q, B, device=0) as mpc:
+                    r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w), want_traj=True)
+                    torch.cuda.synchronize()
+                    st = mpc.stats()
+                    res[cuts] = {k: v.cpu().numpy() for k, v in r.items()}
+                    assert st.batch == B and st.n_success == int((res[cuts]["status"] == 0).sum())
+            for cuts in res:
+                for key in ("out", "traj", "status", "iters"):
+                    assert np.array_equal(res[cuts][key], res[(0, 0, 0, 0)][key]), (prec, cuts, key)
+            assert res[(0, 0, 0, 0)]["iters"].max() > 60     # instances that go through every phase
     finally:
         if old is None:
             os.environ.pop("MPC_PASS_CUT", None)

@@ -216,6 +216,34 @@ def test_park_and_resume_is_bitwise_identical(pkg, host_twin, golden_dir, waypoi
     assert np.array_equal(out, ref["out"]) and np.array_equal(status, ref["status"]) and np.array_equal(iters, ref["iters"])
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_repeated_park_and_resume_is_bitwise_identical(pkg, host_twin, golden_dir, waypoints, f32):
+    """A cut schedule parks an instance several times (MpcParams.pass_cut, pass_cut_next): every 4 passes here, with
+    per-instance weights (the heavy-tailed batch the schedule is made for), in both precisions -- the fp32 solver keeps one
+    more value between passes (the previous output step), which has to travel too."""
+    import ctypes as C
+    from helpers import vp, twin_solve_f32
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 512
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=92)
+    w = pkg.scenarios.weight_sweep(B, params, seed=93)
+    dt = np.float32 if f32 else np.float64
+    if f32:
+        params.precision = pkg.PRECISION_F32
+        ref = twin_solve_f32(host_twin, params, b, weights=w, want_traj=False)
+        fn = host_twin.mpc_host_twin_solve_reparked_f32
+    else:
+        ref = twin_solve(host_twin, params, b, weights=w, want_traj=False)
+        fn = host_twin.mpc_host_twin_solve_reparked
+    a = lambda x: np.ascontiguousarray(x, dtype=dt)
+    st, cf, yl, yh, ww = a(b["state"]), a(b["coeffs"]), a(b["yaw_lo"]), a(b["yaw_hi"]), a(w)
+    out = np.zeros((9, B), dtype=dt); status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32); parked = np.zeros(B, dtype=np.int32)
+    rc = fn(C.byref(params), C.c_int64(B), C.c_int64(B), C.c_int(4), vp(st), vp(cf), vp(yl), vp(yh), vp(ww), vp(out), vp(status), vp(iters), vp(parked))
+    assert rc == 0
+    assert parked.max() >= 10 and (parked >= 2).mean() > 0.8
+    assert np.array_equal(out, np.asarray(ref["out"], dtype=dt)) and np.array_equal(status, ref["status"]) and np.array_equal(iters, ref["iters"])
+
+
 def test_twin_against_scipy_goldens_long_horizon_and_weights(pkg, host_twin, golden_dir):
     gold = load_golden("scipy_cross_solve_ext.json")
     for sel, over in ((lambda c: c["N"] == 25, dict(N=25, dt=0.05)), (lambda c: c["weights"] is not None, {})):
