@@ -70,6 +70,29 @@ def test_f32_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, waypoin
         assert r32["iters"].mean() < r64["iters"].mean()        # the looser tolerance is also fewer iterations
 
 
+@pytest.mark.parametrize("config,N,dt", [("config-stable.json", 25, 0.05), ("config-fast.json", 40, 0.025)])
+def test_f32_long_horizons_are_best_effort(pkg, host_twin, golden_dir, waypoints, config, N, dt):
+    """MPC_PRECISION_F32 is specified for BASELINE.json configs[4] (N = 10).  On long horizons (x reaches 60 m, 150-240
+    constraints) it still works, with this accounting: a few instances per thousand end at the noise floor of single
+    precision without meeting the fp32 tolerance -- the constraint violation cannot go below ~1e-5 there and a Newton step
+    computed from that noise can throw the duals out -- and are REPORTED as such (status LINESEARCH or MAXITER, never
+    silently wrong); everything reported as solved is within looser tolerances of the fp64 build: steer 2e-3 rad, step-1
+    state 2e-2.  (A guard that refuses such steps was tried: it rescues those instances and costs every other one a factor
+    of two in accuracy, so it is not in.)"""
+    params = _f32_params(pkg, golden_dir, config=config, N=N, dt=dt)
+    p64 = params.copy(); p64.precision = pkg.PRECISION_F64
+    B = 1024
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=61)
+    r64 = twin_solve(host_twin, p64, b, want_traj=False)
+    r32 = twin_solve_f32(host_twin, params, b, want_traj=False)
+    assert set(np.unique(r32["status"])) <= {0, 1, 2}
+    assert (r32["status"] != 0).sum() <= 6, np.bincount(r32["status"])
+    ok = (r32["status"] == 0) & (r64["status"] == 0)
+    d = np.abs(r32["out"].astype(np.float64) - r64["out"])[:, ok]
+    assert d[6].max() <= 2e-3 and d[:6].max() <= 2e-2, (d[6].max(), d[:6].max())
+    assert np.quantile(d[6], 0.99) <= 5e-4
+
+
 def test_f32_math_kernels(host_twin):
     """sin/cos/atan of the fp32 solver (polynomial kernels in mpc_core.h)."""
     rng = np.random.default_rng(5)
