@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--inflight", type=int, default=0, help="batches in flight per GPU (handles on separate streams); default: 2 in fp64, "
                     "4 in fp32 (measured best for each)")
+    ap.add_argument("--max-iter", type=int, default=0, help="MpcParams.max_iter (default 200): the iteration cap; instances that reach it are "
+                    "reported with status MAXITER, as the reference returns its iterate at IPOPT's 0.5 s max_cpu_time")
     ap.add_argument("--pass-cuts", default="", help="multi-phase solve (MpcParams.pass_cut, pass_cut_next): up to four comma-separated "
                     "cuts, e.g. 16,16,32 -- instances still running after that many passes are re-packed into dense waves for "
                     "a further launch; bitwise the same results; made for heavy-tailed batches (weight sweeps, long horizons)")
@@ -221,6 +223,8 @@ def main():
     f32 = args.precision == "f32"
     if f32:
         params.precision = pkg.PRECISION_F32
+    if args.max_iter > 0:
+        params.max_iter = args.max_iter
     cuts = [int(c) for c in args.pass_cuts.split(",") if c.strip()][:4]
     if cuts:
         params.pass_cut = cuts[0]
