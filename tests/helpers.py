@@ -131,3 +131,36 @@ def assert_parity(got_out, ref_out, got_traj=None, ref_traj=None, what="", tol_a
 
 def load_golden(name):
     return json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+
+
+def garbage_batch(batch, weights):
+    """Copies of (batch, weights) whose first instances carry inputs no caller should send -- NaN, infinities, 1e300,
+    inverted or empty yaw bounds, negative / infinite / all-zero weights -- one defect per instance.  Returns
+    (batch, weights, names).  What the solver owes such an instance: a status, no hang, and no effect on its neighbours."""
+    b = {k: np.array(batch[k], dtype=np.float64, copy=True) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}
+    w = np.array(weights, dtype=np.float64, copy=True)
+    defects = [
+        ("v0 = nan", lambda i: b["state"].__setitem__((3, i), np.nan)),
+        ("cte0 = inf", lambda i: b["state"].__setitem__((4, i), np.inf)),
+        ("epsi0 = -inf", lambda i: b["state"].__setitem__((5, i), -np.inf)),
+        ("x0 = 1e300", lambda i: b["state"].__setitem__((0, i), 1e300)),
+        ("c0 = nan", lambda i: b["coeffs"].__setitem__((0, i), np.nan)),
+        ("c3 = 1e200", lambda i: b["coeffs"].__setitem__((3, i), 1e200)),
+        ("c1 = inf", lambda i: b["coeffs"].__setitem__((1, i), np.inf)),
+        ("yaw_lo = nan", lambda i: b["yaw_lo"].__setitem__(i, np.nan)),
+        ("yaw_hi = inf", lambda i: b["yaw_hi"].__setitem__(i, np.inf)),
+        ("yaw_lo = -inf", lambda i: b["yaw_lo"].__setitem__(i, -np.inf)),
+        ("yaw_lo > yaw_hi", lambda i: (b["yaw_lo"].__setitem__(i, 1.0), b["yaw_hi"].__setitem__(i, -1.0))),
+        ("yaw_lo == yaw_hi", lambda i: (b["yaw_lo"].__setitem__(i, 0.0), b["yaw_hi"].__setitem__(i, 0.0))),
+        ("v0 = 1e6", lambda i: b["state"].__setitem__((3, i), 1e6)),
+        ("v0 = -5", lambda i: b["state"].__setitem__((3, i), -5.0)),
+        ("psi0 = 1e6", lambda i: b["state"].__setitem__((2, i), 1e6)),
+        ("w[0] = nan", lambda i: w.__setitem__((0, i), np.nan)),
+        ("w[0] = -1", lambda i: w.__setitem__((0, i), -1.0)),
+        ("all weights 0", lambda i: w.__setitem__((slice(None), i), 0.0)),
+        ("w[1] = inf", lambda i: w.__setitem__((1, i), np.inf)),
+        ("w[3] = 1e30", lambda i: w.__setitem__((3, i), 1e30)),
+    ]
+    for i, (_, fn) in enumerate(defects):
+        fn(i)
+    return b, w, [d[0] for d in defects]

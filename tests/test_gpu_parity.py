@@ -446,6 +446,29 @@ def test_multi_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torc
             os.environ["MPC_PASS_CUT"] = old
 
 
+def test_garbage_inputs_get_a_status_and_stay_contained(pkg, host_twin, golden_dir, waypoints, torch_dev):
+    """The same on the device (tests/test_host_twin.py has the CPU build of the same header, which was run first: no
+    input of helpers.garbage_batch makes the state machine loop): every defective instance ends with the status the CPU
+    build gives it, the launch ends, and the clean instances sharing waves with them are solved bit for bit as in a
+    clean batch."""
+    from helpers import garbage_batch, twin_solve
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 4096 + 37
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=5)
+    w = pkg.scenarios.weight_sweep(B, params, seed=3)
+    gb, gw, names = garbage_batch(b, w)
+    n = len(names)
+    clean = gpu_solve(pkg, params, b, torch_dev, weights=w)
+    dirty = gpu_solve(pkg, params, gb, torch_dev, weights=gw)
+    with np.errstate(over="ignore"):
+        ref = twin_solve(host_twin, params, {k: gb[k][..., :n] for k in gb}, weights=gw[:, :n], want_traj=False)
+    # NaN / overflow paths may end in either of the two "could not" codes depending on which operation sees them first
+    same = (dirty["status"][:n] == ref["status"]) | (np.isin(dirty["status"][:n], (2, 4)) & np.isin(ref["status"], (2, 4)))
+    assert same.all(), list(zip(names, dirty["status"][:n], ref["status"]))
+    for k in ("out", "traj", "status", "iters"):
+        assert np.array_equal(dirty[k][..., n:], clean[k][..., n:]), k
+
+
 @pytest.mark.parametrize("N,dt", [(3, 0.1), (4, 0.05), (40, 0.025), (64, 0.02)])
 def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N, dt):
     """The shortest horizons the ABI accepts (N=3: two transitions) and the longest (MPC_MAX_N = 64), ragged batch."""

@@ -244,6 +244,36 @@ def test_repeated_park_and_resume_is_bitwise_identical(pkg, host_twin, golden_di
     assert np.array_equal(out, np.asarray(ref["out"], dtype=dt)) and np.array_equal(status, ref["status"]) and np.array_equal(iters, ref["iters"])
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_garbage_inputs_get_a_status_and_stay_contained(pkg, host_twin, golden_dir, waypoints, f32):
+    """NaN, infinities, 1e300, inverted bounds, negative and infinite weights (helpers.garbage_batch), one defect per
+    instance: every such instance ends with a status (the solve terminates: this test finishing is the assertion), and the
+    clean instances behind them are solved bit for bit as in a clean batch."""
+    from helpers import garbage_batch, twin_solve_f32
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    if f32:
+        params.precision = pkg.PRECISION_F32
+    B = 96
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=5)
+    w = pkg.scenarios.weight_sweep(B, params, seed=3)
+    gb, gw, names = garbage_batch(b, w)
+    solve = (lambda bb, ww: twin_solve_f32(host_twin, params, bb, weights=ww, want_traj=False)) if f32 else \
+            (lambda bb, ww: twin_solve(host_twin, params, bb, weights=ww, want_traj=False))
+    with np.errstate(over="ignore"):
+        clean, dirty = solve(b, w), solve(gb, gw)
+    n = len(names)
+    assert set(np.unique(dirty["status"][:n])) <= {0, 1, 2, 3, 4}
+    st = dict(zip(names, dirty["status"][:n]))
+    for name in ("v0 = nan", "yaw_lo = nan", "yaw_lo > yaw_hi", "yaw_lo == yaw_hi", "v0 = 1e6", "psi0 = 1e6"):
+        assert st[name] == 3, (name, st[name])            # outside its own bounds (or no interior): rejected at set-up
+    for name in ("c0 = nan", "w[0] = nan", "w[1] = inf", "c1 = inf", "epsi0 = -inf"):
+        assert st[name] == 4, (name, st[name])            # not a number somewhere in the first evaluation
+    for name in ("v0 = -5", "w[0] = -1", "all weights 0", "w[3] = 1e30"):
+        assert st[name] == 0, (name, st[name])            # unusual but well-posed (a negative weight is regularised away)
+    for k in ("out", "status", "iters"):
+        assert np.array_equal(dirty[k][..., n:], clean[k][..., n:]), k
+
+
 def test_twin_against_scipy_goldens_long_horizon_and_weights(pkg, host_twin, golden_dir):
     gold = load_golden("scipy_cross_solve_ext.json")
     for sel, over in ((lambda c: c["N"] == 25, dict(N=25, dt=0.05)), (lambda c: c["weights"] is not None, {})):
