@@ -288,7 +288,7 @@ int orc_config_load(const char *path, OrcConfig *c) {
   size_t len = fread(txt, 1, (1 << 16) - 1, f);
   fclose(f); txt[len] = 0;
   orc_config_defaults(c);
-  double v; int rc = 0;
+  double v = 0.0; int rc = 0;
   rc |= json_num(txt, "N", &v); c->N = (int)v;
   rc |= json_num(txt, "dt", &c->dt);
   rc |= json_num(txt, "max acceleration", &v); c->max_acceleration = orc_mph2mps(v);
