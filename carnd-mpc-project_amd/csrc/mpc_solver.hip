@@ -368,7 +368,7 @@ struct MpcHandle {
   int lds_lanes = 0;       /* instances per workgroup of the LDS-resident kernel (0: N too large for it, or MPC_LDS=0) */
   int64_t lds_max_batch = 0;   /* launches up to this size take the LDS-resident kernel: lds_lanes x number of CUs */
   bool occ2 = false;       /* fp32: MPC_F32_OCC=2 selects the build held to 256 registers (two waves per SIMD, ~110 spill reloads per
-                            * pass); the unconstrained build (280 registers, one wave per SIMD) measured 7 % faster on the final code */
+                            * pass); the unconstrained build (296 registers, one wave per SIMD) measured 7 % faster on the final code */
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
   void *ws = nullptr;
   hipStream_t stream = nullptr;
@@ -462,7 +462,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     }                                                                                   \
   } while (0)
   h->params = *p; h->device = device; h->max_batch = max_batch;
-  /* Launch shape: each workgroup is one wave; the fp64 kernel needs 378 registers, so at most one wave runs
+  /* Launch shape: each workgroup is one wave; the fp64 kernel needs ~390 registers, so at most one wave runs
    * per SIMD (4 per CU), and the 36 KB of staging LDS per wave fit four times into a CU's 160 KB (fp32: 256
    * registers, two waves per SIMD, 20 KB each).
    * MPC_STAGING=0 selects the variant with ordinary loads (for A/B measurements). */
