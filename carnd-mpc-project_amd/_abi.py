@@ -67,7 +67,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
-           "mpc_wire_telemetry_batch_host"]
+           "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool"]
 
 _lib = None
 
@@ -117,6 +117,7 @@ def library():
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]
     L.mpc_debug_math.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 4
     L.mpc_debug_math_ext.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 6
+    L.mpc_debug_tile_pool.argtypes = [C.c_void_p, C.c_void_p]
     L.mpc_run_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
     L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
                                              [C.c_void_p])

@@ -110,6 +110,12 @@ struct MpcPhase {
    * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
    * waiting, or `refill_wait` passes have gone by, or nothing else is running; then all of them are served at once. */
   int32_t refill_min, refill_wait;
+  /* Tile pool (MpcTilePool, optional): instead of tile number blockIdx of the handle's own workspace a wave takes a free
+   * tile from the pool of ITS XCD and gives it back when it leaves, so that the addresses the device cycles through are
+   * the tiles of the resident waves and not those of every batch in flight. */
+  unsigned long long *pool_bits;   /* [8][pool_words]: bit set = tile free; nullptr = no pool */
+  void *pool_base;                 /* [8][pool_tiles] tiles */
+  int32_t pool_tiles, pool_words;  /* per XCD */
 };
 
 /* OCC = waves per SIMD the register allocation is held to: the fp64 solver needs ~380 registers (1); the fp32 solver
@@ -128,6 +134,39 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   static_assert(SV::PARK_N == kParkRows, "park buffer rows");
   WS ws;
   ws.tile = (typename WS::greal *)(wsbase + (int64_t)blockIdx.x * tile_reals);
+#if defined(__HIP_DEVICE_COMPILE__)
+  int pool_word = -1, pool_bit = 0;
+  unsigned long long *pool_mine = nullptr;
+  if (T.pool_bits) {
+    /* first free tile of this XCD's pool (lowest number first: the set of tiles in use stays compact); a tile is only
+     * ever used by waves of one XCD, so everything written to it sits in one L2.  No free tile (cannot happen while the
+     * pool holds more tiles than an XCD has wave slots): the wave keeps its own tile of the handle's workspace. */
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   /* HW_REG_XCC_ID[3:0] */
+    pool_mine = T.pool_bits + (size_t)xcc * (size_t)T.pool_words;
+    int got = -1;
+    if (threadIdx.x == 0) {
+      for (int w = 0; w < T.pool_words && got < 0; ++w) {
+        unsigned long long v = __hip_atomic_load(pool_mine + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (v) {
+          const int b = __builtin_ctzll(v);
+          const unsigned long long m = 1ull << b;
+          const unsigned long long old = atomicAnd(pool_mine + w, ~m);
+          if (old & m) { got = w * 64 + b; break; }
+          v = old & ~m;
+        }
+      }
+    }
+    got = __builtin_amdgcn_readfirstlane(got);
+    if (got >= 0 && threadIdx.x == 0) {      /* usage record for mpc_debug_tile_pool: claims, highest tile number + 1 */
+      atomicAdd(pool_mine + T.pool_words - 2, 1ull);
+      atomicMax(pool_mine + T.pool_words - 1, (unsigned long long)(got + 1));
+    }
+    if (got >= 0) {
+      pool_word = got >> 6; pool_bit = got & 63;
+      ws.tile = (typename WS::greal *)((R *)T.pool_base + ((int64_t)xcc * T.pool_tiles + got) * tile_reals);
+    }
+  }
+#endif
   ws.lane = threadIdx.x;
   ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
@@ -215,6 +254,13 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
       }
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (pool_word >= 0) {
+    /* every store of this wave to the tile has been acknowledged before the tile can be handed on */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) atomicOr(pool_mine + pool_word, 1ull << pool_bit);
+  }
+#endif
 }
 
 /* Small launches: the N-step variables of every instance resident in LDS (mpc::LdsWorkspace), one instance per lane,
@@ -359,6 +405,51 @@ __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, do
 
 }  // namespace
 
+/* One pool of workspace tiles per (device, tile size), shared by every handle created with MPC_TILE_POOL=1 */
+struct MpcTilePool {
+  int device = 0;
+  size_t tile_bytes = 0;
+  int tiles = 0, words = 0;        /* per XCD */
+  void *base = nullptr;
+  unsigned long long *bits = nullptr;
+  int refs = 0;
+};
+static std::mutex g_pool_mutex;
+static std::vector<MpcTilePool *> g_pools;
+
+static MpcTilePool *pool_acquire(int device, size_t tile_bytes, int tiles_per_xcd) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  for (MpcTilePool *p : g_pools)
+    if (p->device == device && p->tile_bytes == tile_bytes && p->tiles == tiles_per_xcd) { ++p->refs; return p; }
+  MpcTilePool *p = new MpcTilePool();
+  p->device = device; p->tile_bytes = tile_bytes; p->tiles = tiles_per_xcd; p->words = (tiles_per_xcd + 63) / 64;
+  /* every XCD's words on cache lines of their own; the last two words of an XCD are its usage record */
+  p->words = (p->words + 2 + 15) / 16 * 16;
+  if (hipMalloc(&p->base, tile_bytes * (size_t)tiles_per_xcd * 8) != hipSuccess ||
+      hipMalloc((void **)&p->bits, sizeof(unsigned long long) * (size_t)p->words * 8) != hipSuccess) {
+    if (p->base) (void)hipFree(p->base);
+    delete p;
+    return nullptr;
+  }
+  std::vector<unsigned long long> init((size_t)p->words * 8, 0ull);
+  for (int x = 0; x < 8; x++)
+    for (int t = 0; t < tiles_per_xcd; t++) init[(size_t)x * p->words + t / 64] |= 1ull << (t % 64);
+  if (hipMemcpy(p->bits, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p->base); (void)hipFree(p->bits); delete p; return nullptr;
+  }
+  p->refs = 1;
+  g_pools.push_back(p);
+  return p;
+}
+static void pool_release(MpcTilePool *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (--p->refs > 0) return;
+  for (size_t i = 0; i < g_pools.size(); i++) if (g_pools[i] == p) { g_pools.erase(g_pools.begin() + i); break; }
+  (void)hipFree(p->base); (void)hipFree(p->bits);
+  delete p;
+}
+
 struct MpcHandle {
   MpcParams params;
   int device = 0;
@@ -393,6 +484,7 @@ struct MpcHandle {
   void *ws2 = nullptr;
   double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
+  MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
   /* last call */
   int64_t last_B = 0;
   bool timed = false;
@@ -432,6 +524,25 @@ static int validate_params(const MpcParams *p) {
 }
 
 extern "C" int mpc_abi_version(void) { return MPC_ABI_VERSION; }
+
+/* state of the handle's tile pool: per XCD (free tiles now, tiles in the pool, claims so far, highest tile number used + 1) */
+extern "C" int mpc_debug_tile_pool(MpcHandle *h, int64_t *out32) {
+  if (!h || !out32) return MPC_ERR_INVALID;
+  for (int q = 0; q < 32; q++) out32[q] = 0;
+  if (!h->pool) { g_last_error = "no tile pool on this handle (MPC_TILE_POOL=1 at mpc_create)"; return MPC_ERR_UNSUPPORTED; }
+  MPC_ON_DEVICE(h);
+  MPC_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<unsigned long long> bits((size_t)h->pool->words * 8);
+  MPC_HIP_CHECK(hipMemcpy(bits.data(), h->pool->bits, bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int x = 0; x < 8; x++) {
+    const unsigned long long *b = bits.data() + (size_t)x * h->pool->words;
+    int64_t fr = 0;
+    for (int t = 0; t < h->pool->tiles; t++) fr += (b[t / 64] >> (t % 64)) & 1ull;
+    out32[4 * x + 0] = fr; out32[4 * x + 1] = h->pool->tiles;
+    out32[4 * x + 2] = (int64_t)b[h->pool->words - 2]; out32[4 * x + 3] = (int64_t)b[h->pool->words - 1];
+  }
+  return MPC_OK;
+}
 extern "C" const char *mpc_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, MpcHandle **out) {
@@ -511,6 +622,16 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   set_cuts(h, p);
+  if (const char *ep = getenv("MPC_TILE_POOL")) {
+    if (atoi(ep) > 0) {
+      /* tiles per XCD: its wave slots for this kernel (CUs / 8 XCDs x 4 SIMDs x waves per SIMD) and a margin */
+      const int per_xcd = prop.multiProcessorCount / 8 * 4 * ((f32 && h->occ2) ? 2 : 1);
+      int extra = 16;
+      if (const char *ex = getenv("MPC_TILE_POOL_EXTRA")) extra = atoi(ex);
+      h->pool = pool_acquire(device, (size_t)h->ws_stride * (f32 ? sizeof(float) : sizeof(double)), per_xcd + (extra > 0 ? extra : 0));
+      if (!h->pool) { g_last_error = "hipMalloc(tile pool)"; mpc_destroy(h); return MPC_ERR_HIP; }
+    }
+  }
   if (const char *e3 = getenv("MPC_PHASE_MIN_BATCH")) { h->two_phase_min = atoll(e3); if (h->two_phase_min < 1) h->two_phase_min = 1; }
   if (const char *e4 = getenv("MPC_REFILL_MIN")) { h->refill_min = atoi(e4); if (h->refill_min < 1) h->refill_min = 1; }
   if (const char *e5 = getenv("MPC_REFILL_WAIT")) { h->refill_wait = atoi(e5); if (h->refill_wait < 0) h->refill_wait = 0; }
@@ -545,6 +666,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_rstat) (void)hipFree(h->d_rstat);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->ws2) (void)hipFree(h->ws2);
+  pool_release(h->pool);
   if (h->d_park) (void)hipFree(h->d_park);
   if (h->d_list) (void)hipFree(h->d_list);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -657,6 +779,9 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
     T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    const bool pooled = h->pool && n_cuts == 0;      /* a parked iterate stays in its column: phases keep their own tiles */
+    T.pool_bits = pooled ? h->pool->bits : nullptr; T.pool_base = pooled ? h->pool->base : nullptr;
+    T.pool_tiles = pooled ? h->pool->tiles : 0; T.pool_words = pooled ? h->pool->words : 0;
     launch((unsigned)waves, wr ? h->ws2 : h->ws, T);
     MPC_HIP_CHECK(hipGetLastError());
   }

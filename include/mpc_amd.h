@@ -247,6 +247,11 @@ int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
 int mpc_debug_math(int device, int64_t n, const double *x, double *sn, double *cs, double *rc);
 /* the same plus at[i] = atan(x[i]) and lg[i] = log|x[i]| (the solver's own atan and log kernels) */
 int mpc_debug_math_ext(int device, int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg);
+/* Tile pool (MPC_TILE_POOL=1 in the environment of mpc_create): instead of the handle's own workspace the
+ * waves of a launch take their tile from a pool of the XCD they run on, shared by all handles of that device and tile
+ * size.  out32[4 x + 0..3] for XCD x = free tiles now, tiles in the pool, claims so far, highest tile number used + 1.
+ * Synchronises the device.  MPC_ERR_UNSUPPORTED when the handle has no pool. */
+int mpc_debug_tile_pool(MpcHandle *h, int64_t *out32);
 
 #ifdef __cplusplus
 }

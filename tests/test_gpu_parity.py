@@ -446,6 +446,53 @@ def test_multi_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torc
             os.environ["MPC_PASS_CUT"] = old
 
 
+def test_tile_pool_is_bitwise_identical_and_used(pkg, golden_dir, waypoints, torch_dev):
+    """MPC_TILE_POOL=1: waves take their workspace tile from a per-XCD pool shared by all handles instead of their
+    handle's own workspace.  Three handles on three streams, several rounds without a pause in between (so tiles change
+    hands between launches that are running): every launch must give the plain path's results bit for bit, every tile must
+    be back in the pool afterwards, and every wave must have got one."""
+    import torch
+    import ctypes as C
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    old = os.environ.get("MPC_TILE_POOL")
+    try:
+        for prec, dt_, B, sweep in ((pkg.PRECISION_F64, torch.float64, 32768 + 70, False), (pkg.PRECISION_F32, torch.float32, 16384, True)):
+            q = params.copy(); q.precision = prec
+            b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=7)
+            w = pkg.scenarios.weight_sweep(B, q, seed=8) if sweep else None
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=dt_)
+            ins = (t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]))
+            wt = t(w) if w is not None else None
+            os.environ.pop("MPC_TILE_POOL", None)
+            with pkg.BatchedMPC(q, B, device=0) as mpc:
+                ref = {k: v.cpu().numpy() for k, v in mpc.solve_torch(*ins, weights=wt, want_traj=True).items()}
+            os.environ["MPC_TILE_POOL"] = "1"
+            hs = [pkg.BatchedMPC(q, B, device=0) for _ in range(3)]
+            streams = [torch.cuda.Stream(device=torch_dev) for _ in hs]
+            rounds, outs = 4, []
+            for _ in range(rounds):
+                for h, s_ in zip(hs, streams):
+                    with torch.cuda.stream(s_):
+                        outs.append(h.solve_torch(*ins, weights=wt, want_traj=True))
+            torch.cuda.synchronize()
+            for o in outs:
+                for key in ("out", "traj", "status", "iters"):
+                    assert np.array_equal(o[key].cpu().numpy(), ref[key]), (prec, key)
+            st = np.zeros(32, dtype=np.int64)
+            assert pkg.library().mpc_debug_tile_pool(hs[0]._h, C.c_void_p(st.ctypes.data)) == 0
+            st = st.reshape(8, 4)
+            assert (st[:, 0] == st[:, 1]).all(), st                       # every tile is back
+            assert st[:, 2].sum() == rounds * len(hs) * ((B + 63) // 64), st   # every wave got one (no wave fell back)
+            assert (st[:, 3] <= st[:, 1]).all() and (st[:, 3] > 0).all(), st
+            for h in hs:
+                h.close()
+    finally:
+        if old is None:
+            os.environ.pop("MPC_TILE_POOL", None)
+        else:
+            os.environ["MPC_TILE_POOL"] = old
+
+
 def test_garbage_inputs_get_a_status_and_stay_contained(pkg, host_twin, golden_dir, waypoints, torch_dev):
     """The same on the device (tests/test_host_twin.py has the CPU build of the same header, which was run first: no
     input of helpers.garbage_batch makes the state machine loop): every defective instance ends with the status the CPU
