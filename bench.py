@@ -76,7 +76,7 @@ def parse_args(argv=None):
                     "reported with status MAXITER, as the reference returns its iterate at IPOPT's 0.5 s max_cpu_time")
     ap.add_argument("--pass-cuts", default="", help="multi-phase solve (MpcParams.pass_cut, pass_cut_next): up to four comma-separated "
                     "cuts, e.g. 16,16,32 -- instances still running after that many passes are re-packed into dense waves for "
-                    "a further launch; bitwise the same results; made for heavy-tailed batches (weight sweeps, long horizons)")
+                    "a further launch; bitwise the same results (measured: no gain in time per batch, DESIGN.md 6c)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     ap.add_argument("--force-collective", action="store_true", help="one rank only: initialise RCCL with world size 1 and run the per-batch "

@@ -113,7 +113,8 @@ typedef struct MpcParams {
                               * 0.6 tol_f32; see DESIGN.md, fp32 mode) */
   int32_t polish;            /* default 1 */
   int32_t pass_cut_next[3];  /* further cuts (passes counted from the previous cut; a zero ends the list), e.g.
-                              * pass_cut 16, next {16, 32, 0}: four launches, made for heavy-tailed batches */
+                              * pass_cut 16, next {16, 32, 0}: four launches (0.3x the wave passes of a heavy-tailed
+                              * batch; measured: no gain in time per batch) */
   double reserved_d[2];
 } MpcParams;
 
