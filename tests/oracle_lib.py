@@ -245,3 +245,19 @@ def solve_chunk(job):
                 cfg.weights[q] = float(w[q, i])
         mpc_solve(cfg, state[:, i], coeffs[:, i])
     return n
+
+
+def solve_chunk_full(job):
+    """Worker of tests/test_soak.py: like solve_chunk, but returns the oracle's results (out [9,n], traj [2N,n], status, iterations)."""
+    name, over, state, coeffs, ylo, yhi, w = job
+    cfg = load_config(name, **over)
+    n = state.shape[1]
+    out = np.zeros((9, n)); traj = np.zeros((2 * cfg.N, n)); status = np.zeros(n, dtype=np.int32); iters = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        cfg.yaw_low, cfg.yaw_high = float(ylo[i]), float(yhi[i])
+        if w is not None:
+            for q in range(12):
+                cfg.weights[q] = float(w[q, i])
+        st, o9, tx, ty, info = mpc_solve(cfg, state[:, i], coeffs[:, i])
+        out[:, i] = o9; traj[:cfg.N, i] = tx; traj[cfg.N:, i] = ty; status[i] = st; iters[i] = info.iterations
+    return out, traj, status, iters

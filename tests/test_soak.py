@@ -1,0 +1,62 @@
+"""Soak: whole batches on the device against the ORACLE, every instance (not a sample), the oracle spread over the host's
+cores.  Opt-in (MPC_SOAK=1: it needs a minute of 16 cores); the report goes to gpurun_out/soak.json and is kept under
+profiles/.  Sizes: MPC_SOAK_SCALE (default 1.0) times 65 536 headline / 32 768 weight-sweep / 8 192 long-horizon instances."""
+import json
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import TOL_ACCEL, TOL_COST_REL, TOL_STEER, TOL_TRAJ
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("MPC_SOAK"), reason="opt-in: MPC_SOAK=1")]
+
+
+def _oracle_all(config, over, b, w, workers):
+    B = b["state"].shape[1]
+    n_chunks = workers * 8
+    edges = np.linspace(0, B, n_chunks + 1).astype(int)
+    jobs = [(config, over, b["state"][:, lo:hi], b["coeffs"][:, lo:hi], b["yaw_lo"][lo:hi], b["yaw_hi"][lo:hi], None if w is None else w[:, lo:hi])
+            for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(O.solve_chunk_full, jobs)
+    return {"out": np.concatenate([p[0] for p in parts], axis=1), "traj": np.concatenate([p[1] for p in parts], axis=1),
+            "status": np.concatenate([p[2] for p in parts]), "iters": np.concatenate([p[3] for p in parts])}
+
+
+def test_soak_whole_batches_against_the_oracle(pkg, golden_dir, waypoints):
+    import torch
+    dev = torch.device("cuda:0")
+    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
+    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    report = {"what": "device (mpc_solve_batch_device, fp64, default parameters) against oracle/mpc_oracle.c on EVERY instance of a batch", "workers": workers, "workloads": []}
+    for name, config, over, B, sweep, seed in (("headline (configs[2])", "config-fast.json", {}, int(65536 * scale), False, 101),
+                                               ("weight sweep", "config-fast.json", {}, int(32768 * scale), True, 102),
+                                               ("long horizon N=25 dt=0.05 (configs[3])", "config-stable.json", dict(N=25, dt=0.05), int(8192 * scale), False, 103)):
+        params = pkg.params_from_json(os.path.join(golden_dir, config), **over)
+        b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=seed)
+        w = pkg.scenarios.weight_sweep(B, params, seed=seed + 50) if sweep else None
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        with pkg.BatchedMPC(params, B, device=0) as mpc:
+            r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w) if w is not None else None, want_traj=True)
+            torch.cuda.synchronize()
+            got = {k: v.cpu().numpy() for k, v in r.items()}
+        ref = _oracle_all(config, over, {k: np.ascontiguousarray(b[k], dtype=np.float64) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}, w, workers)
+        same_status = got["status"] == ref["status"]
+        ok = (got["status"] == 0) & (ref["status"] == 0)
+        d = np.abs(got["out"] - ref["out"])[:, ok]
+        dt_ = np.abs(got["traj"] - ref["traj"])[:, ok].max(0)
+        dc = d[8] / np.maximum(1.0, np.abs(ref["out"][8][ok]))
+        q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.999, 1.0)]
+        row = {"workload": name, "instances": B, "status_device": np.bincount(got["status"], minlength=5).tolist(), "status_oracle": np.bincount(ref["status"], minlength=5).tolist(),
+               "status_differs": int((~same_status).sum()), "both_converged": int(ok.sum()),
+               "same_iteration_count": float((got["iters"][ok] == ref["iters"][ok]).mean()), "max_iteration_difference": int(np.abs(got["iters"][ok] - ref["iters"][ok]).max()),
+               "quantiles": "p50, p99, p99.9, max", "d_steer_rad": q(d[6]), "d_accel": q(d[7]), "d_step1_state": q(d[:6].max(0)), "d_trajectory_m": q(dt_), "d_cost_rel": q(dc)}
+        report["workloads"].append(row)
+        print(json.dumps(row))
+        assert row["status_differs"] == 0, row
+        assert d[6].max() <= TOL_STEER and d[7].max() <= TOL_ACCEL and d[:6].max() <= TOL_TRAJ and dt_.max() <= TOL_TRAJ and dc.max() <= TOL_COST_REL, row
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/soak.json", "w"), indent=1)
