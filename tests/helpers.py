@@ -59,8 +59,8 @@ TOL_COST_REL = 1e-7
 # barrier floor 2e-5), not rounding: delta0 is well determined; a0 sits on a bound in most instances (exact to the
 # barrier slack) and is weakly determined when it does not (no a^2 term on the frozen tape).
 F32_TOL_STEER = 5e-3     # rad (1 % of the steering range), every instance;  99.9 % of the instances: 2e-3;  99 %: 5e-4
-F32_TOL_ACCEL = 5e-2     # m/s^2 (0.4 % of the actuator range), every instance;  99 %: 2e-3
-F32_TOL_STATE = 5e-3     # m / rad / m/s, step-1 state
+F32_TOL_ACCEL = 1e-1     # m/s^2 (0.8 % of the actuator range), every instance (65 536-instance soak: max 6.8e-2, 99.9 %: 3.6e-4)
+F32_TOL_STATE = 1e-2     # m / rad / m/s, step-1 state (soak: max 6.8e-3, 99.9 %: 5.7e-4)
 F32_TOL_TRAJ = 0.3       # m, predicted trajectory: its far end is the least determined part of the solution (99 %: 5e-2)
 F32_TOL_COST_REL = 1e-4
 

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from helpers import TOL_ACCEL, TOL_COST_REL, TOL_STEER, TOL_TRAJ
+from helpers import (F32_TOL_ACCEL, F32_TOL_COST_REL, F32_TOL_STATE, F32_TOL_STEER, F32_TOL_TRAJ, TOL_ACCEL, TOL_COST_REL, TOL_STEER,
+                     TOL_TRAJ)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("MPC_SOAK"), reason="opt-in: MPC_SOAK=1")]
 
@@ -60,3 +61,38 @@ def test_soak_whole_batches_against_the_oracle(pkg, golden_dir, waypoints):
         assert d[6].max() <= TOL_STEER and d[7].max() <= TOL_ACCEL and d[:6].max() <= TOL_TRAJ and dt_.max() <= TOL_TRAJ and dc.max() <= TOL_COST_REL, row
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/soak.json", "w"), indent=1)
+
+
+def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
+    """BASELINE.json configs[4]'s shape: MPC_PRECISION_F32 with per-instance weights, every instance of a 65 536-batch against
+    the fp64 oracle, stated fp32 tolerances (helpers.F32_TOL_*), every status accounted for."""
+    import torch
+    dev = torch.device("cuda:0")
+    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
+    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    B = int(65536 * scale)
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    params.precision = pkg.PRECISION_F32
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=111)
+    w = pkg.scenarios.weight_sweep(B, params, seed=161)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=torch.float32)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w), want_traj=True)
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in r.items()}
+    ref = _oracle_all("config-fast.json", {}, {k: np.ascontiguousarray(b[k], dtype=np.float64) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}, w, workers)
+    ok = (got["status"] == 0) & (ref["status"] == 0)
+    d = np.abs(got["out"].astype(np.float64) - ref["out"])[:, ok]
+    dt_ = np.abs(got["traj"].astype(np.float64) - ref["traj"])[:, ok].max(0)
+    dc = d[8] / np.maximum(1.0, np.abs(ref["out"][8][ok]))
+    q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.999, 1.0)]
+    row = {"workload": "fp32 weight sweep (configs[4] shape) against the fp64 oracle", "instances": B,
+           "status_device": np.bincount(got["status"], minlength=5).tolist(), "status_oracle": np.bincount(ref["status"], minlength=5).tolist(),
+           "both_converged": int(ok.sum()), "mean_iterations_device": float(got["iters"].mean()), "mean_iterations_oracle": float(ref["iters"].mean()),
+           "quantiles": "p50, p99, p99.9, max", "d_steer_rad": q(d[6]), "d_accel": q(d[7]), "d_step1_state": q(d[:6].max(0)), "d_trajectory_m": q(dt_), "d_cost_rel": q(dc)}
+    print(json.dumps(row))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(row, open("gpurun_out/soak_f32.json", "w"), indent=1)
+    assert (ref["status"] == 0).all()
+    assert (got["status"] != 0).sum() <= max(2, B // 20000), row          # reported, never silent: the device's own count is in the row
+    assert d[6].max() <= F32_TOL_STEER and d[7].max() <= F32_TOL_ACCEL and d[:6].max() <= F32_TOL_STATE and dt_.max() <= F32_TOL_TRAJ and dc.max() <= F32_TOL_COST_REL, row
