@@ -261,3 +261,31 @@ def solve_chunk_full(job):
         st, o9, tx, ty, info = mpc_solve(cfg, state[:, i], coeffs[:, i])
         out[:, i] = o9; traj[:cfg.N, i] = tx; traj[cfg.N:, i] = ty; status[i] = st; iters[i] = info.iterations
     return out, traj, status, iters
+
+
+def run_chunk_full(job):
+    """Worker of tests/test_soak.py: the oracle's MPC::run() on poses + waypoints -> (status [n], out8 [8,n])."""
+    name, over, pose, ptsx, ptsy = job
+    n = pose.shape[1]
+    out8 = np.zeros((8, n)); status = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        cfg = load_config(name, **over)          # run() mutates the yaw bounds of its Config, like the reference
+        st, o8, _, _, _, _ = mpc_run(cfg, pose[:, i], ptsx[:, i], ptsy[:, i])
+        out8[:, i] = o8; status[i] = st
+    return status, out8
+
+
+def rollout_chunk_full(job):
+    """Worker of tests/test_soak.py: closed loops of `steps` oracle solves (src/test.cpp:79-111) -> (worst status [n], hist [steps,9,n])."""
+    name, over, state, coeffs, ylo, yhi, steps = job
+    cfg = load_config(name, **over)
+    n = state.shape[1]
+    hist = np.zeros((steps, 9, n)); worst = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        cfg.yaw_low, cfg.yaw_high = float(ylo[i]), float(yhi[i])
+        s = list(state[:, i])
+        for t in range(steps):
+            st, o9, _, _, _ = mpc_solve(cfg, s, coeffs[:, i])
+            hist[t, :, i] = o9; worst[i] = max(worst[i], st)
+            s = list(o9[:6])
+    return worst, hist

@@ -96,3 +96,79 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
     assert (ref["status"] == 0).all()
     assert (got["status"] != 0).sum() <= max(2, B // 20000), row          # reported, never silent: the device's own count is in the row
     assert d[6].max() <= F32_TOL_STEER and d[7].max() <= F32_TOL_ACCEL and d[:6].max() <= F32_TOL_STATE and dt_.max() <= F32_TOL_TRAJ and dc.max() <= F32_TOL_COST_REL, row
+
+
+def _chunks(B, workers):
+    edges = np.linspace(0, B, workers * 8 + 1).astype(int)
+    return [(lo, hi) for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
+
+
+def test_soak_run_and_closed_loop_against_the_oracle(pkg, golden_dir, waypoints):
+    """SURVEY 8f rows on whole batches: MPC::run() (fit, solve, post-processing) for 16 384 poses, and 25-step closed loops
+    (src/test.cpp:79-111) for 2 048 cars, every instance against the oracle doing the same."""
+    import torch
+    dev = torch.device("cuda:0")
+    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
+    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    cfgname = "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    report = {}
+    # ---- run()
+    B = int(16384 * scale)
+    tel = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=121)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.run_torch(t(tel["pose"]), t(tel["ptsx"]), t(tel["ptsy"]))
+        torch.cuda.synchronize()
+        out8 = r["out8"].cpu().numpy(); status = r["status"].cpu().numpy()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(O.run_chunk_full, [(cfgname, {}, c(tel["pose"][:, lo:hi]), c(tel["ptsx"][:, lo:hi]), c(tel["ptsy"][:, lo:hi])) for lo, hi in _chunks(B, workers)])
+    rst = np.concatenate([p[0] for p in parts]); ref8 = np.concatenate([p[1] for p in parts], axis=1)
+    ok = (status == 0) & (rst == 0)
+    d = np.abs(out8 - ref8)[:, ok]
+    report["run"] = {"instances": B, "status_differs": int((status != rst).sum()), "both_converged": int(ok.sum()),
+                     "d_steer_rad_max": float(d[4].max() * params.max_steering), "d_throttle_accel_max": float(d[5].max()),
+                     "d_state_max": float(d[[0, 1, 2, 3, 6, 7]].max())}
+    print(json.dumps(report["run"]))
+    assert report["run"]["status_differs"] == 0
+    assert report["run"]["d_steer_rad_max"] <= TOL_STEER and report["run"]["d_throttle_accel_max"] <= TOL_ACCEL and report["run"]["d_state_max"] <= TOL_TRAJ
+    # ---- closed loops
+    B, steps = int(2048 * scale), 25
+    sc = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=122)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        ro = mpc.rollout_torch(t(sc["state"]), t(sc["coeffs"]), t(sc["yaw_lo"]), t(sc["yaw_hi"]), steps=steps)
+        torch.cuda.synchronize()
+        hist = ro["hist"].cpu().numpy(); status = ro["status"].cpu().numpy()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(O.rollout_chunk_full, [(cfgname, {}, c(sc["state"][:, lo:hi]), c(sc["coeffs"][:, lo:hi]), c(sc["yaw_lo"][lo:hi]), c(sc["yaw_hi"][lo:hi]), steps)
+                                               for lo, hi in _chunks(B, workers)])
+    worst = np.concatenate([p[0] for p in parts]); oh = np.concatenate([p[1] for p in parts], axis=2)
+    # A car whose heading has reached a yaw bound (they are fixed for the whole loop while the road turns: the reference's
+    # own 30-01-2.png shows it) starts its next solve ON the bound, 1e-12 inside: a problem whose answer is decided by the
+    # last bits of the previous one.  From there on the two solvers are no longer solving the same problem; the comparison
+    # covers every car up to the step at which its heading first comes within 1e-6 of a bound.
+    psi_d = np.concatenate([sc["state"][2][None], hist[:, 2]]); psi_o = np.concatenate([sc["state"][2][None], oh[:, 2]])
+    marg = np.minimum(np.minimum(sc["yaw_hi"] - psi_d, psi_d - sc["yaw_lo"]), np.minimum(sc["yaw_hi"] - psi_o, psi_o - sc["yaw_lo"]))   # [steps+1, B]
+    on_bound = marg < 1e-6
+    first = np.where(on_bound.any(0), on_bound.argmax(0), steps + 1)      # hist[t] is comparable while t < first (its start state was clear)
+    valid = np.arange(steps)[:, None] < first[None, :]
+    free = first > steps                                                   # cars that never touch a bound
+    same = (status == 0) == (worst == 0)
+    d = np.abs(hist - oh)
+    pick = lambda rows: (d[:, rows].max(1) if isinstance(rows, slice) else d[:, rows])[valid]
+    q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.999, 1.0)]
+    report["closed_loop"] = {"cars": B, "steps": steps, "solves": B * steps, "cars_never_on_a_yaw_bound": int(free.sum()),
+                             "solves_compared": int(valid.sum()), "status_class_differs_among_free_cars": int((~same & free).sum()),
+                             "device_status_counts": np.bincount(status, minlength=5).tolist(), "oracle_status_counts": np.bincount(worst, minlength=5).tolist(),
+                             "quantiles": "p50, p99, p99.9, max over the compared solves", "d_steer_rad": q(pick(6)), "d_accel": q(pick(7)), "d_state": q(pick(slice(0, 6)))}
+    print(json.dumps(report["closed_loop"]))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/soak_8f.json", "w"), indent=1)
+    cl = report["closed_loop"]
+    assert cl["status_class_differs_among_free_cars"] == 0
+    assert cl["solves_compared"] > 0.4 * B * steps and cl["cars_never_on_a_yaw_bound"] > B // 8
+    # Closed loop: what one solve leaves (<= 1e-6) is fed back up to 25 times and the loop's own dynamics act on it, so the
+    # single-solve tolerances hold for 99.9 % of the compared solves and the worst one is within 50x of them.
+    assert cl["d_steer_rad"][2] <= 2 * TOL_STEER and cl["d_accel"][2] <= 2 * TOL_ACCEL and cl["d_state"][2] <= 2 * TOL_TRAJ, cl
+    assert cl["d_steer_rad"][3] <= 50 * TOL_STEER and cl["d_accel"][3] <= 50 * TOL_ACCEL and cl["d_state"][3] <= 50 * TOL_TRAJ, cl
