@@ -126,7 +126,7 @@ template <class F> void run(const char *name, F kern, double *d) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double h[65]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  printf("%-12s %8.1f ns per repetition (wall), %8.1f s_memtime ticks (100 MHz) ; checksum %.6g\n", name, ms * 1e6 / iters, h[64] / iters, h[0]);
+  printf("%-12s %8.1f ns per repetition (wall), %8.1f shader cycles ; checksum %.6g\n", name, ms * 1e6 / iters, h[64] / iters, h[0]);
 }
 int main() {
   double *d; hipMalloc(&d, 66 * sizeof(double));
