@@ -12,7 +12,7 @@ NCOEF = 5
 NSTATE = 6
 NOUT = 9
 MAX_N = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRECISION_F64, PRECISION_F32 = 0, 1
 
 STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric"}
@@ -39,7 +39,10 @@ class MpcParams(C.Structure):
         ("ipopt_timeout", C.c_double), ("branch_mode", C.c_int32), ("precision", C.c_int32),
         ("max_iter", C.c_int32), ("pass_cut", C.c_int32), ("tol", C.c_double),
         ("out_step_tol", C.c_double), ("tol_f32", C.c_double), ("polish", C.c_int32),
-        ("pass_cut_next", C.c_int32 * 3), ("reserved_d", C.c_double * 2),
+        ("pass_cut_next", C.c_int32 * 3), ("honor_original_bounds", C.c_int32), ("bound_relax_factor", C.c_double),
+        ("tail_cut", C.c_int32), ("tail_ring", C.c_int32), ("tail_capacity", C.c_int64),
+        ("f32_finish", C.c_int32), ("f64_f32_start", C.c_int32), ("mixed_switch_mu", C.c_double),
+        ("reserved_d", C.c_double * 2),
     ]
 
     def copy(self):

@@ -608,11 +608,21 @@ struct Solver {
   WS ws;
   /* instance data */
   R st[6], coef[MPC_NCOEF], yl, yu;
-  R wc, we, wv, wd, wdd, vref, cost0;
+  R wc, we, wv, wd, wdd, vref, cost0, vref0, w9v;
   /* bounds */
   R vl, vu, dl, du, al, au;
   int M;       /* number of stages = N-1 */
   R dt, dtLf, iLf, psi_start;
+  /* psi_0 and v_0 as IPOPT sees them.  In the reference's NLP the initial state is not data: vars[k*N] are VARIABLES
+   * (with the bounds of their blocks, MPC.cpp:229-239) pinned by equality rows (MPC.cpp:116-121, 269-281).  IPOPT
+   * pushes a start value that lies within kappa1/kappa2 of a bound into the interior, and the Newton steps then bring
+   * it back at the pace the fraction-to-the-boundary rule allows: x0^{k+1} = x0^k + alpha_k (state - x0^k).  For the four
+   * unbounded components that never does anything; psi_0 (a closed loop whose heading has reached its bound,
+   * test.cpp:79-111) and v_0 (a car at Config::maxSpeed) take a few iterations, during which stage 0 is linearised at
+   * (psi_0^k, v_0^k), its residual counts in theta and its slacks limit the step.  These two scalars carry exactly that;
+   * the multipliers of the six pinning rows and the bound duals of psi_0, v_0 (which decouple: the rows hold a free
+   * multiplier with unit coefficient) are not carried. */
+  R p0, v0k;
   /* interior-point state */
   int cur;     /* slot of the current iterate */
   R mu, tau, df;
@@ -691,10 +701,17 @@ struct Solver {
     if (k == 0) {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) s[i] = st[i];
+      s[2] = p0; s[3] = v0k;
     } else {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) s[i] = ws.it(k - 1, I, F_S + i);
     }
+  }
+  /* IPOPT's push of a start value into the interior of its (relaxed) bounds, W&B section 3.6 */
+  MPC_HD R pushed(R x, R lo, R hi) const {
+    const R pl = mpc_min(IC::kappa1 * mpc_max(R(1.0), mpc_abs(lo)), IC::kappa2 * (hi - lo));
+    const R pu = mpc_min(IC::kappa1 * mpc_max(R(1.0), mpc_abs(hi)), IC::kappa2 * (hi - lo));
+    return mpc_min(mpc_max(x, lo + pl), hi - pu);
   }
 
   /* ------------------------------------------------------------------ */
@@ -761,6 +778,7 @@ struct Solver {
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = st[i];
+        sk[2] = p0; sk[3] = v0k;
       }
       const R v = sk[3];
       LinR L;
@@ -804,7 +822,7 @@ struct Solver {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) { w5[i] = Bp * (PM(i, 2) + PM(i, 4)) + PM(i, 5); w6[i] = dt * PM(i, 3); }
       if (k == 0) {
-        /* only the feed-forward of u_0 is needed (ds_0 = 0) */
+        /* the feed-forward of u_0, and the feedback on the only components of ds_0 that can be non-zero: psi_0, v_0 */
         R o5[7], o6[7];
         MPC_GT(w5, R(0.0), o5);
         MPC_GT(w6, R(0.0), o6);
@@ -814,10 +832,13 @@ struct Solver {
         const R det = Rdd * Raa - Rda * Rda;
         if (!(Rdd > R(0.0)) || !(det > R(0.0))) return false;
         const R idet = frcp1(det);
-        static_assert(F_GF % F::G == 0, "kff starts a group");
-        R gf[F::G] = {};
-        gf[0] = -(Raa * rt_d - Rda * rt_a) * idet; gf[1] = -(-Rda * rt_d + Rdd * rt_a) * idet;
-        ws.template store_run<F_GF, F::G>(0, J, gf);
+        const R i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
+        const R Sd2 = o5[2], Sd3 = o5[3] - (lp + le) * dtLf, Sa2 = o6[2], Sa3 = o6[3];   /* S~ columns of psi_0, v_0 (with the Lagrangian Hessian's d-v term) */
+        R gn[GAIN_SZ] = {};
+        gn[2] = -(i11 * Sd2 + i12 * Sa2); gn[3] = -(i11 * Sd3 + i12 * Sa3);
+        gn[6 + 2] = -(i12 * Sd2 + i22 * Sa2); gn[6 + 3] = -(i12 * Sd3 + i22 * Sa3);
+        gn[GK_N] = -(Raa * rt_d - Rda * rt_a) * idet; gn[GK_N + 1] = -(-Rda * rt_d + Rdd * rt_a) * idet;
+        ws.template store_run<F_GK, GAIN_SZ>(0, J, gn);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -933,6 +954,16 @@ struct Solver {
     dphi = R(0.0); dxinf = R(0.0); xinf = R(0.0);
     R sk[6];
     load_state(0, I, sk);
+    /* ds_0: the pinning rows are linear, the full step restores them (zero for an instance whose start was not pushed) */
+    d2 = rsc * (st[2] - p0); d3 = rsc * (st[3] - v0k);
+    if (d2 != R(0.0) || d3 != R(0.0)) {
+      /* psi_0 and v_0 are bounded variables: their slacks limit the step and their barrier and cost terms are part of
+       * the merit function's slope */
+      const R islp = frcp1(p0 - yl), isup = frcp1(yu - p0), islv = frcp1(v0k - vl), isuv = frcp1(vu - v0k);
+      rmax = mpc_max(mpc_max(-d2 * islp, d2 * isup), mpc_max(-d3 * islv, d3 * isuv));
+      dphi = mu * ((isup - islp) * d2 + (isuv - islv) * d3) + df * dcost0_dv(v0k) * d3;
+      dxinf = mpc_max(mpc_abs(d2), mpc_abs(d3));
+    }
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
     ws.stage_fetch_itf(0, 0, I);
@@ -959,6 +990,9 @@ struct Solver {
               ws.sg(bf, k, J, 4) * d5 + ws.sg(bf, k, J, 5) * ddprev;
         da += ws.sg(bf, k, J, 6) * d0 + ws.sg(bf, k, J, 7) * d1 + ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3 +
               ws.sg(bf, k, J, 10) * d5 + ws.sg(bf, k, J, 11) * ddprev;
+      } else if (d2 != R(0.0) || d3 != R(0.0)) {
+        dd += ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3;
+        da += ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3;
       }
       const R vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const R n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
@@ -1149,6 +1183,18 @@ struct Solver {
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
+        s_o[2] = p0; s_o[3] = v0k;
+        s_t[2] = trial_x0(p0, st[2], alpha); s_t[3] = trial_x0(v0k, st[3], alpha);
+        const R c2 = s_t[2] - st[2], c3 = s_t[3] - st[3];    /* residuals of the pinning rows of psi_0, v_0 */
+        if (c2 != R(0.0) || c3 != R(0.0)) {
+          Ev.theta += mpc_abs(c2) + mpc_abs(c3); Ev.cinf = mpc_max(Ev.cinf, mpc_max(mpc_abs(c2), mpc_abs(c3)));
+          const R slp = s_t[2] - yl, sup = yu - s_t[2], slv = s_t[3] - vl, suv = vu - s_t[3];
+          if (!(slp > R(0.0)) || !(sup > R(0.0)) || !(slv > R(0.0)) || !(suv > R(0.0))) Ev.ok = false;
+          /* barrier and cost terms of (psi_0, v_0) RELATIVE to their values at the pinned point, which are constants
+           * of the merit function like the rest of the stage-0 cost */
+          Ev.L += flog((slp * sup * slv * suv) * frcp((st[2] - yl) * (yu - st[2]) * (st[3] - vl) * (vu - st[3])));
+          Ev.f += cost0_of_v(s_t[3]) - cost0_of_v(st[3]);
+        }
       }
       if (k < M) {
         /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
@@ -1194,6 +1240,12 @@ struct Solver {
     if (!(Ev.theta == Ev.theta) || !(Ev.f == Ev.f) || !(Ev.L == Ev.L) || !(Ev.dinf == Ev.dinf)) Ev.ok = false;
     return Ev;
   }
+
+  /* a pinned start value after a step of length alpha; exactly the pinned value once it has arrived */
+  MPC_HD R trial_x0(R x0, R pinned, R alpha_) const { return x0 == pinned ? pinned : x0 + alpha_ * (pinned - x0); }
+  /* the v_0 part of the stage-0 cost (MPC.cpp:87-92 at i = 0, branches as taped at xi) and its derivative */
+  MPC_HD R cost0_of_v(R v) const { const R e = v - vref0; return wv * e * e + w9v * v * v; }
+  MPC_HD R dcost0_dv(R v) const { return R(2.0) * wv * (v - vref0) + R(2.0) * w9v * v; }
 
   MPC_HD R kkt_error(const EvalR &e, R mu_) const {
     const R m = R(6.0) * M, nb = R(8.0) * M;
@@ -1250,10 +1302,16 @@ struct Solver {
     for (int i = 0; i < 6; i++) st[i] = state6[i];
     MPC_UNROLL
     for (int i = 0; i < MPC_NCOEF; i++) coef[i] = coef5[i];
-    yl = yaw_lo; yu = yaw_hi;
     M = P.N - 1; dt = (R)P.dt; iLf = (R)(1.0 / P.Lf); dtLf = (R)(P.dt / P.Lf);
-    vl = (R)-P.max_speed; vu = (R)P.max_speed; dl = (R)-P.max_steering; du = (R)P.max_steering;
-    al = (R)P.max_deceleration; au = (R)P.max_acceleration;
+    /* IPOPT's bound_relax_factor (default 1e-8, untouched by MPC.cpp:160-179): every finite variable bound is moved
+     * outwards by factor * max(1, |bound|) before the solve; the start point is pushed inside the RELAXED bounds and
+     * the returned point is projected back into the caller's (unpack).  This is what makes a solve that starts ON a
+     * bound well posed: the psi_0 of a closed loop whose heading has reached yawHigh (test.cpp:79-111). */
+    const double rf = P.bound_relax_factor;
+    yl = (R)((double)yaw_lo - rf * fmax(1.0, fabs((double)yaw_lo))); yu = (R)((double)yaw_hi + rf * fmax(1.0, fabs((double)yaw_hi)));
+    vu = (R)(P.max_speed + rf * fmax(1.0, P.max_speed)); vl = -vu;
+    du = (R)(P.max_steering + rf * fmax(1.0, P.max_steering)); dl = -du;
+    al = (R)(P.max_deceleration - rf * fmax(1.0, fabs(P.max_deceleration))); au = (R)(P.max_acceleration + rf * fmax(1.0, fabs(P.max_acceleration)));
     fth0 = fth1 = fth2 = fth3 = fph0 = fph1 = fph2 = fph3 = R(0.0);
     lsm = false; cur = 0; iters = 0; n_reg = 0; nf = 0; E.f = R(0.0);
     /* fp32: its own tolerance; the outputs cannot stop moving below the noise of an fp32 step */
@@ -1272,11 +1330,12 @@ struct Solver {
     /* i = 0 terms: constants of the objective (their variables are fixed), MPC.cpp:71-92 */
     const R wc0 = ((double)mpc_abs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
     const R we0 = ((double)mpc_abs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
-    const R vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
+    vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
     cost0 = wc0 * st[4] * st[4] + we0 * st[5] * st[5] + wv * (st[3] - vref0) * (st[3] - vref0);
     R g0 = mpc_max(mpc_abs(R(2.0) * wc0 * st[4]), mpc_abs(R(2.0) * we0 * st[5]));
     R gv0 = R(2.0) * wv * (st[3] - vref0);
-    if (st[3] < R(0.0)) { cost0 += w12[9] * st[3] * st[3]; gv0 += R(2.0) * w12[9] * st[3]; }
+    w9v = R(0.0);
+    if (st[3] < R(0.0)) { w9v = w12[9]; cost0 += w12[9] * st[3] * st[3]; gv0 += R(2.0) * w12[9] * st[3]; }
     g0 = mpc_max(g0, mpc_abs(gv0));
     /* gradient-based objective scaling at the start point (IPOPT default) */
     g0 = mpc_max(g0, mpc_abs(R(2.0) * wv * vref));
@@ -1339,7 +1398,7 @@ struct Solver {
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
     a(22) = (R)nf; a(23) = (R)iter; a(24) = (R)n_reg; a(25) = (R)cur; a(26) = E.ok ? R(1.0) : R(0.0);
     a(27) = ls_start ? R(1.0) : R(0.0); a(28) = (R)attempt; a(29) = (R)it_total;
-    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(33) = R(0.0); a(34) = R(0.0); a(35) = R(0.0);
+    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(33) = p0; a(34) = v0k; a(35) = R(0.0);
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
     begin(a(27) != R(0.0));
@@ -1347,7 +1406,7 @@ struct Solver {
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
     nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != R(0.0);
-    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32);
+    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32); p0 = a(33); v0k = a(34);
     iters = iter; phase = PH_DIR;
   }
 
@@ -1357,6 +1416,7 @@ struct Solver {
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
     phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = out_prev = IC::huge;
+    p0 = pushed(st[2], yl, yu); v0k = pushed(st[3], vl, vu);
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
     theta_max = theta_min = dw_last = R(0.0);
     theta_k = phi_k = pth = pdp = amin = R(0.0);
@@ -1498,6 +1558,7 @@ struct Solver {
       if (!ftype) filter_add((R(1.0) - IC::gamma_theta) * theta_k, phi_k - IC::gamma_phi * theta_k);
       cur = 1 - cur;
       E = T;
+      p0 = trial_x0(p0, st[2], alpha); v0k = trial_x0(v0k, st[3], alpha);
       /* fp32: the outputs must have been still for two steps in a row (steps are noisy and can be short for other reasons) */
       /* what the polish watches: the step of the outputs (delta_0, a_0), and 0.03 x the largest step of any primal variable
        * -- the predicted trajectory, whose far end is the least determined part of the solution, has then moved by less than
@@ -1517,13 +1578,23 @@ struct Solver {
   }
 
   /* MPC.cpp:306-324: out9 and the optional N-point trajectory */
+  /* yaw_lo / yaw_hi: the caller's psi-bounds of this instance (the solver itself holds the relaxed ones): with
+   * honor_original_bounds (IPOPT 3.12 default "yes") the returned point is projected into the bounds the user gave */
   template <class OutF, class TrajF>
-  MPC_HD void unpack(OutF out, TrajF traj, bool want_traj) const {
+  MPC_HD void unpack(OutF out, TrajF traj, bool want_traj, R yaw_lo, R yaw_hi) const {
     const int I = it(cur);
     MPC_UNROLL
     for (int i = 0; i < 6; i++) out(i) = ws.it(0, I, F_S + i);
     out(6) = ws.it(0, I, F_U + 0);
     out(7) = ws.it(0, I, F_U + 1);
+    if (P.honor_original_bounds) {
+      const R psi1 = ws.it(0, I, F_S + 2), v1 = ws.it(0, I, F_S + 3), d0 = ws.it(0, I, F_U + 0), a0 = ws.it(0, I, F_U + 1);
+      /* written so that a NaN passes through unchanged */
+      out(2) = psi1 < yaw_lo ? yaw_lo : (psi1 > yaw_hi ? yaw_hi : psi1);
+      out(3) = v1 < (R)-P.max_speed ? (R)-P.max_speed : (v1 > (R)P.max_speed ? (R)P.max_speed : v1);
+      out(6) = d0 < (R)-P.max_steering ? (R)-P.max_steering : (d0 > (R)P.max_steering ? (R)P.max_steering : d0);
+      out(7) = a0 < (R)P.max_deceleration ? (R)P.max_deceleration : (a0 > (R)P.max_acceleration ? (R)P.max_acceleration : a0);
+    }
     out(8) = E.f + cost0;
     if (want_traj) {
       const int N = P.N;
@@ -1543,7 +1614,7 @@ MPC_HD int solve_instance(const MpcParams &P, WS ws, const R *state6, const R *c
   if (status == MPC_STATUS_SUCCESS) status = S.solve();
   R *o = out9;
   R *t = traj2N;
-  S.unpack([o](int i) -> R & { return o[i]; }, [t](int i) -> R & { return t[i]; }, traj2N != nullptr);
+  S.unpack([o](int i) -> R & { return o[i]; }, [t](int i) -> R & { return t[i]; }, traj2N != nullptr, yaw_lo, yaw_hi);
   if (iters_out) *iters_out = S.iters;
   return status;
 }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           R *o = out + i;
           R *t = traj ? traj + i : nullptr;
           const int64_t l = ldo;
-          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
+          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
           status[i] = fin_status;
           if (iters) iters[i] = S.iters + it_total;
           fin = false;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
   R *o = out + i;
   R *t = traj ? traj + i : nullptr;
   const int64_t l = ldo;
-  S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr);
+  S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
   status[i] = r;
   if (iters) iters[i] = S.iters;
 }
@@ -516,6 +516,7 @@ static int validate_params(const MpcParams *p) {
   if (p->n_steers < 0 || p->n_steers > MPC_MAX_TABLE || p->n_steer_speeds < 1 || p->n_steer_speeds > MPC_MAX_TABLE) { g_last_error = "bad steer tables"; return MPC_ERR_INVALID; }
   if (p->n_yaw_changes < 0 || p->n_yaw_changes > MPC_MAX_TABLE || p->n_yaw_change_speeds < 0 || p->n_yaw_change_speeds > MPC_MAX_TABLE) { g_last_error = "bad yaw-change tables"; return MPC_ERR_INVALID; }
   if (!(p->out_step_tol >= 0)) { g_last_error = "bad out_step_tol"; return MPC_ERR_INVALID; }
+  if (!(p->bound_relax_factor >= 0 && p->bound_relax_factor <= 1e-3)) { g_last_error = "bad bound_relax_factor (IPOPT default 1e-8)"; return MPC_ERR_INVALID; }
   if (p->branch_mode != MPC_BRANCH_FROZEN) { g_last_error = "branch_mode LIVE is not implemented on the device path"; return MPC_ERR_UNSUPPORTED; }
   if (p->precision != MPC_PRECISION_F64 && p->precision != MPC_PRECISION_F32) { g_last_error = "unknown precision"; return MPC_ERR_INVALID; }
   if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }

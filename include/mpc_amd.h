@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 2
+#define MPC_ABI_VERSION 3
 #define MPC_MAX_TABLE 16
 #define MPC_NW 12      /* Config::weights entries read by FG_eval (Config.h:14-61) */
 #define MPC_NCOEF 5    /* road polynomial, zero padded: fit order is 2..4 (RoadGeometry.cpp:26-34) */
@@ -115,6 +115,27 @@ typedef struct MpcParams {
   int32_t pass_cut_next[3];  /* further cuts (passes counted from the previous cut; a zero ends the list), e.g.
                               * pass_cut 16, next {16, 32, 0}: four launches (0.3x the wave passes of a heavy-tailed
                               * batch; measured: no gain in time per batch) */
+  /* IPOPT defaults the reference's option string (MPC.cpp:160-179) leaves untouched and that shape the answer when a
+   * solve starts on a bound (closed loops, test.cpp:79-111): every finite variable bound is relaxed by
+   * bound_relax_factor * max(1, |bound|) before the solve, and the returned point is projected back into the caller's
+   * bounds (honor_original_bounds = yes in IPOPT 3.12). */
+  int32_t honor_original_bounds;   /* default 1 */
+  double bound_relax_factor;       /* default 1e-8 */
+  /* Deferred tails: a launch lasts as long as its slowest instance.  With tail_cut > 0 an instance that
+   * is still running after tail_cut passes is handed to the handle's tail queue (status MPC_STATUS_PENDING) and the
+   * launch ends; the queue is drained by a separate launch on the handle's own tail stream while later batches run.
+   * mpc_tail_wait / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
+  int32_t tail_cut;                /* default 0 = off */
+  int32_t tail_ring;               /* batches whose tails may be outstanding at once, default 16 */
+  int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 8.  A batch with more keeps the rest in its launch */
+  /* Mixed precision across phases.  MPC_PRECISION_F32 handles: f32_finish = 1 (default) runs the interior-point
+   * iteration in fp32 until its barrier parameter has reached mixed_switch_mu and finishes every instance in fp64
+   * (same state machine, tol instead of tol_f32, termination polish), fp32 at the ABI; 0 = the pure fp32 solver.
+   * MPC_PRECISION_F64 handles: f64_f32_start = 1 runs the same early iterations on the fp32 record (half the
+   * workspace bytes) before the fp64 solve takes over; default 0. */
+  int32_t f32_finish;
+  int32_t f64_f32_start;
+  double mixed_switch_mu;          /* default 2e-5 */
   double reserved_d[2];
 } MpcParams;
 

@@ -697,6 +697,7 @@ void orc_default_options(OrcSolveOptions *o) {
   o->branch_mode = ORC_BRANCH_FROZEN; o->max_iter = 500; o->tol = 1e-8;
   o->lam_init_ls = 1; o->obj_scaling = 1; o->verbose = 0;
   o->polish = 1; o->out_step_tol = 3e-7;
+  o->bound_relax_factor = 1e-8; o->honor_original_bounds = 1;
 }
 
 typedef struct Filter { double th[256], ph[256]; int n; } Filter;
@@ -737,6 +738,23 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   Filter *flt = (Filter *)malloc(sizeof(Filter));
   int nb = 0, status = ORC_MAXITER_EXCEEDED;
   memset(info, 0, sizeof(*info));
+
+  /* IPOPT option bound_relax_factor (default 1e-8; the reference's option string MPC.cpp:160-179 leaves it alone):
+   * "before start of the optimization, the bounds given by the user are relaxed" -- OrigIpoptNLP::relax_bounds of
+   * IPOPT 3.12: x_L -= factor * max(1, |x_L|), x_U += factor * max(1, |x_U|) for every finite variable bound
+   * (equality constraints are not touched).  The whole iteration, the push of the start point included, sees the
+   * relaxed bounds; the caller's are restored on return, and the final point is projected back into them
+   * (honor_original_bounds, default "yes" in 3.12).  It matters exactly when a solve starts ON a bound: the fixed
+   * psi_0 of a closed loop whose heading has reached yawHigh (test.cpp:79-111, examples/30-01-2.png) has slack 1e-12
+   * against its own variable bound without it, and 1e-8 with it. */
+  double *xl_user = P->xl, *xu_user = P->xu;
+  double *xl_rel = (double *)malloc(szn), *xu_rel = (double *)malloc(szn);
+  for (int i = 0; i < n; i++) {
+    xl_rel[i] = xl_user[i]; xu_rel[i] = xu_user[i];
+    if (xl_user[i] > -ORC_INF_BOUND) xl_rel[i] -= opt->bound_relax_factor * fmax(1.0, fabs(xl_user[i]));
+    if (xu_user[i] < ORC_INF_BOUND) xu_rel[i] += opt->bound_relax_factor * fmax(1.0, fabs(xu_user[i]));
+  }
+  P->xl = xl_rel; P->xu = xu_rel;
 
   for (int i = 0; i < n; i++) {
     hl[i] = P->xl[i] > -ORC_INF_BOUND; hu[i] = P->xu[i] < ORC_INF_BOUND; nb += hl[i] + hu[i];
@@ -898,6 +916,13 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     int tiny = dxn <= 10 * DBL_EPSILON * fmax(1.0, xn);
     for (;;) {
       for (int i = 0; i < n; i++) xt[i] = x[i] + alpha * dx[i];
+      /* The fraction-to-the-boundary rule keeps every slack positive in exact arithmetic; with tau = 1 - mu = 1 - 1e-9 a
+       * slack of 4e-8 is asked to shrink to 4e-17, below the spacing of doubles at x ~ 1, and x + alpha dx lands ON the
+       * bound.  IPOPT repairs such slacks (CalculateSafeSlack moves the bound by ~eps); restated here, as in the device
+       * solver, as "a trial point without strictly positive slacks is not acceptable": the step is halved. */
+      int inside = 1;
+      for (int i = 0; i < n; i++) if ((hl[i] && !(xt[i] - P->xl[i] > 0)) || (hu[i] && !(P->xu[i] - xt[i] > 0))) inside = 0;
+      if (!inside && !tiny) { alpha *= 0.5; info->n_backtracks++; if (alpha < amin) break; continue; }
       EVAL_C(xt, ct);
       double theta_t = 0; for (int j = 0; j < m; j++) theta_t += fabs(ct[j]);
       double phi_t = barrier_phi(P, xt, df * eval_f(P->cfg, &P->tape, xt), mu);
@@ -945,6 +970,10 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
 #undef COMPL
 #undef EVAL_C
   info->status = status;
+  P->xl = xl_user; P->xu = xu_user;
+  if (opt->honor_original_bounds)   /* OrigIpoptNLP::FinalizeSolution: the returned x lies inside the bounds the user gave */
+    for (int i = 0; i < n; i++) x[i] = fmin(fmax(x[i], xl_user[i]), xu_user[i]);
+  free(xl_rel); free(xu_rel);
   if (lam_out) memcpy(lam_out, lam, szm);
   free(lam); free(zl); free(zu); free(g); free(c); free(J); free(W); free(K); free(rhs); free(sol);
   free(dzl); free(dzu); free(xt); free(ct); free(hl); free(hu); free(F.perm); free(F.blk); free(flt);
@@ -985,7 +1014,9 @@ int orc_mpc_solve(const OrcConfig *cfg, const OrcSolveOptions *opt_in, const dou
   solve_bounds(cfg, state, xi, xl, xu, gb);
   OrcSolveInfo info; memset(&info, 0, sizeof(info));
   int status;
-  if (state[2] < cfg->yaw_low || state[2] > cfg->yaw_high || fabs(state[3]) > cfg->max_speed) {
+  const double rf = opt.bound_relax_factor;
+  if (state[2] < cfg->yaw_low - rf * fmax(1.0, fabs(cfg->yaw_low)) || state[2] > cfg->yaw_high + rf * fmax(1.0, fabs(cfg->yaw_high)) ||
+      fabs(state[3]) > cfg->max_speed + rf * fmax(1.0, cfg->max_speed)) {
     /* fixed initial state outside its own variable bounds: the reference NLP is infeasible */
     status = ORC_INFEASIBLE_START; info.status = status; memcpy(x, xi, sizeof(double) * I.n);
     tape_decide(cfg, xi, &P.tape); info.obj = eval_f(cfg, &P.tape, x);

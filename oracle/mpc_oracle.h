@@ -92,6 +92,11 @@ typedef struct OrcSolveOptions {
    * as MpcParams.polish / out_step_tol of include/mpc_amd.h.) */
   int polish;
   double out_step_tol;
+  /* IPOPT defaults the reference leaves untouched (MPC.cpp:160-179): every finite variable bound is relaxed by
+   * bound_relax_factor * max(1, |bound|) before the solve (1e-8), and the returned point is projected back into the
+   * caller's bounds (honor_original_bounds = yes, the IPOPT 3.12 default). */
+  double bound_relax_factor;
+  int honor_original_bounds;
 } OrcSolveOptions;
 
 typedef struct OrcSolveInfo {

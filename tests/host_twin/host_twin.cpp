@@ -143,7 +143,7 @@ static int solve_parked_t(const MpcParams *p, int64_t B, int64_t ld, int pass_cu
     }
     R o9[9];
     R *o = o9;
-    fin->unpack([o](int q) -> R & { return o[q]; }, [o](int) -> R & { return o[0]; }, false);
+    fin->unpack([o](int q) -> R & { return o[q]; }, [o](int) -> R & { return o[0]; }, false, yaw_lo[i], yaw_hi[i]);
     for (int q = 0; q < 9; q++) out[q * ld + i] = o9[q];
     status[i] = s; iters[i] = fin->iters;
   }

