@@ -70,7 +70,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
-           "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool"]
+           "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device"]
 
 _lib = None
 
@@ -125,6 +125,8 @@ def library():
     L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
                                              [C.c_void_p])
     L.mpc_rollout_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
+    L.mpc_telemetry_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 4
+    L.mpc_handle_device.argtypes = [C.c_void_p]
     L.mpc_wire_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(MpcWireTelemetry)]
     L.mpc_wire_format_steer.argtypes = [C.c_double, C.c_double, C.c_char_p, C.c_int64]
     L.mpc_wire_format_steer.restype = C.c_int64

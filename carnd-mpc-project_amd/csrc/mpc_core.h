@@ -608,7 +608,7 @@ struct Solver {
   WS ws;
   /* instance data */
   R st[6], coef[MPC_NCOEF], yl, yu;
-  R wc, we, wv, wd, wdd, vref, cost0, vref0, w9v;
+  R wc, we, wv, wd, wdd, vref, cost0;
   /* bounds */
   R vl, vu, dl, du, al, au;
   int M;       /* number of stages = N-1 */
@@ -621,8 +621,14 @@ struct Solver {
    * test.cpp:79-111) and v_0 (a car at Config::maxSpeed) take a few iterations, during which stage 0 is linearised at
    * (psi_0^k, v_0^k), its residual counts in theta and its slacks limit the step.  These two scalars carry exactly that;
    * the multipliers of the six pinning rows and the bound duals of psi_0, v_0 (which decouple: the rows hold a free
-   * multiplier with unit coefficient) are not carried. */
+   * multiplier with unit coefficient) are not carried.  -DMPC_S0_VARIABLE=0 builds the solver with the initial state as
+   * plain data (A/B measurements only). */
+#ifndef MPC_S0_VARIABLE
+#define MPC_S0_VARIABLE 1
+#endif
+#if MPC_S0_VARIABLE
   R p0, v0k;
+#endif
   /* interior-point state */
   int cur;     /* slot of the current iterate */
   R mu, tau, df;
@@ -701,7 +707,9 @@ struct Solver {
     if (k == 0) {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) s[i] = st[i];
+#if MPC_S0_VARIABLE
       s[2] = p0; s[3] = v0k;
+#endif
     } else {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) s[i] = ws.it(k - 1, I, F_S + i);
@@ -778,7 +786,9 @@ struct Solver {
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) sk[i] = st[i];
+#if MPC_S0_VARIABLE
         sk[2] = p0; sk[3] = v0k;
+#endif
       }
       const R v = sk[3];
       LinR L;
@@ -954,6 +964,7 @@ struct Solver {
     dphi = R(0.0); dxinf = R(0.0); xinf = R(0.0);
     R sk[6];
     load_state(0, I, sk);
+#if MPC_S0_VARIABLE
     /* ds_0: the pinning rows are linear, the full step restores them (zero for an instance whose start was not pushed) */
     d2 = rsc * (st[2] - p0); d3 = rsc * (st[3] - v0k);
     if (d2 != R(0.0) || d3 != R(0.0)) {
@@ -961,9 +972,10 @@ struct Solver {
        * the merit function's slope */
       const R islp = frcp1(p0 - yl), isup = frcp1(yu - p0), islv = frcp1(v0k - vl), isuv = frcp1(vu - v0k);
       rmax = mpc_max(mpc_max(-d2 * islp, d2 * isup), mpc_max(-d3 * islv, d3 * isuv));
-      dphi = mu * ((isup - islp) * d2 + (isuv - islv) * d3) + df * dcost0_dv(v0k) * d3;
+      dphi = mu * ((isup - islp) * d2 + (isuv - islv) * d3);
       dxinf = mpc_max(mpc_abs(d2), mpc_abs(d3));
     }
+#endif
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
     ws.stage_fetch_itf(0, 0, I);
@@ -985,15 +997,11 @@ struct Solver {
       LinR L;
       linearise(sk, delta, acc, sn, L);
       R dd = ws.sg(bf, k, J, GK_N + 0), da = ws.sg(bf, k, J, GK_N + 1);
-      if (k > 0) {
-        dd += ws.sg(bf, k, J, 0) * d0 + ws.sg(bf, k, J, 1) * d1 + ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3 +
-              ws.sg(bf, k, J, 4) * d5 + ws.sg(bf, k, J, 5) * ddprev;
-        da += ws.sg(bf, k, J, 6) * d0 + ws.sg(bf, k, J, 7) * d1 + ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3 +
-              ws.sg(bf, k, J, 10) * d5 + ws.sg(bf, k, J, 11) * ddprev;
-      } else if (d2 != R(0.0) || d3 != R(0.0)) {
-        dd += ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3;
-        da += ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3;
-      }
+      /* (stage 0: the record holds zeros except for the columns of psi_0, v_0, and ds_0 is zero elsewhere) */
+      dd += ws.sg(bf, k, J, 0) * d0 + ws.sg(bf, k, J, 1) * d1 + ws.sg(bf, k, J, 2) * d2 + ws.sg(bf, k, J, 3) * d3 +
+            ws.sg(bf, k, J, 4) * d5 + ws.sg(bf, k, J, 5) * ddprev;
+      da += ws.sg(bf, k, J, 6) * d0 + ws.sg(bf, k, J, 7) * d1 + ws.sg(bf, k, J, 8) * d2 + ws.sg(bf, k, J, 9) * d3 +
+            ws.sg(bf, k, J, 10) * d5 + ws.sg(bf, k, J, 11) * ddprev;
       const R vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
       const R n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
       const R n1 = d1 + vdt * L.cp * d2 + dt * L.sp * d3 - rsc * L.c[1];
@@ -1183,6 +1191,7 @@ struct Solver {
       } else {
         MPC_UNROLL
         for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
+#if MPC_S0_VARIABLE
         s_o[2] = p0; s_o[3] = v0k;
         s_t[2] = trial_x0(p0, st[2], alpha); s_t[3] = trial_x0(v0k, st[3], alpha);
         const R c2 = s_t[2] - st[2], c3 = s_t[3] - st[3];    /* residuals of the pinning rows of psi_0, v_0 */
@@ -1190,11 +1199,12 @@ struct Solver {
           Ev.theta += mpc_abs(c2) + mpc_abs(c3); Ev.cinf = mpc_max(Ev.cinf, mpc_max(mpc_abs(c2), mpc_abs(c3)));
           const R slp = s_t[2] - yl, sup = yu - s_t[2], slv = s_t[3] - vl, suv = vu - s_t[3];
           if (!(slp > R(0.0)) || !(sup > R(0.0)) || !(slv > R(0.0)) || !(suv > R(0.0))) Ev.ok = false;
-          /* barrier and cost terms of (psi_0, v_0) RELATIVE to their values at the pinned point, which are constants
-           * of the merit function like the rest of the stage-0 cost */
+          /* barrier terms of (psi_0, v_0) RELATIVE to their values at the pinned point, which are constants of the merit
+           * function like the stage-0 cost.  (The cost's own dependence on v_0, w_v (v_0 - vref_0)^2, is left a constant:
+           * a pushed v_0 sits at Config::maxSpeed, where vref_0 is, so its slope there is ~0.) */
           Ev.L += flog((slp * sup * slv * suv) * frcp((st[2] - yl) * (yu - st[2]) * (st[3] - vl) * (vu - st[3])));
-          Ev.f += cost0_of_v(s_t[3]) - cost0_of_v(st[3]);
         }
+#endif
       }
       if (k < M) {
         /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
@@ -1243,10 +1253,6 @@ struct Solver {
 
   /* a pinned start value after a step of length alpha; exactly the pinned value once it has arrived */
   MPC_HD R trial_x0(R x0, R pinned, R alpha_) const { return x0 == pinned ? pinned : x0 + alpha_ * (pinned - x0); }
-  /* the v_0 part of the stage-0 cost (MPC.cpp:87-92 at i = 0, branches as taped at xi) and its derivative */
-  MPC_HD R cost0_of_v(R v) const { const R e = v - vref0; return wv * e * e + w9v * v * v; }
-  MPC_HD R dcost0_dv(R v) const { return R(2.0) * wv * (v - vref0) + R(2.0) * w9v * v; }
-
   MPC_HD R kkt_error(const EvalR &e, R mu_) const {
     const R m = R(6.0) * M, nb = R(8.0) * M;
     const R sd = mpc_max(IC::s_max, (e.lsum + e.zsum) / (m + nb)) / IC::s_max;
@@ -1330,12 +1336,11 @@ struct Solver {
     /* i = 0 terms: constants of the objective (their variables are fixed), MPC.cpp:71-92 */
     const R wc0 = ((double)mpc_abs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
     const R we0 = ((double)mpc_abs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
-    vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
+    const R vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
     cost0 = wc0 * st[4] * st[4] + we0 * st[5] * st[5] + wv * (st[3] - vref0) * (st[3] - vref0);
     R g0 = mpc_max(mpc_abs(R(2.0) * wc0 * st[4]), mpc_abs(R(2.0) * we0 * st[5]));
     R gv0 = R(2.0) * wv * (st[3] - vref0);
-    w9v = R(0.0);
-    if (st[3] < R(0.0)) { w9v = w12[9]; cost0 += w12[9] * st[3] * st[3]; gv0 += R(2.0) * w12[9] * st[3]; }
+    if (st[3] < R(0.0)) { cost0 += w12[9] * st[3] * st[3]; gv0 += R(2.0) * w12[9] * st[3]; }
     g0 = mpc_max(g0, mpc_abs(gv0));
     /* gradient-based objective scaling at the start point (IPOPT default) */
     g0 = mpc_max(g0, mpc_abs(R(2.0) * wv * vref));
@@ -1398,7 +1403,12 @@ struct Solver {
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
     a(22) = (R)nf; a(23) = (R)iter; a(24) = (R)n_reg; a(25) = (R)cur; a(26) = E.ok ? R(1.0) : R(0.0);
     a(27) = ls_start ? R(1.0) : R(0.0); a(28) = (R)attempt; a(29) = (R)it_total;
-    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(33) = p0; a(34) = v0k; a(35) = R(0.0);
+    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(35) = R(0.0);
+#if MPC_S0_VARIABLE
+    a(33) = p0; a(34) = v0k;
+#else
+    a(33) = R(0.0); a(34) = R(0.0);
+#endif
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
     begin(a(27) != R(0.0));
@@ -1406,7 +1416,10 @@ struct Solver {
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
     nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != R(0.0);
-    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32); p0 = a(33); v0k = a(34);
+    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32);
+#if MPC_S0_VARIABLE
+    p0 = a(33); v0k = a(34);
+#endif
     iters = iter; phase = PH_DIR;
   }
 
@@ -1416,7 +1429,9 @@ struct Solver {
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
     phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = out_prev = IC::huge;
+#if MPC_S0_VARIABLE
     p0 = pushed(st[2], yl, yu); v0k = pushed(st[3], vl, vu);
+#endif
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
     theta_max = theta_min = dw_last = R(0.0);
     theta_k = phi_k = pth = pdp = amin = R(0.0);
@@ -1558,7 +1573,9 @@ struct Solver {
       if (!ftype) filter_add((R(1.0) - IC::gamma_theta) * theta_k, phi_k - IC::gamma_phi * theta_k);
       cur = 1 - cur;
       E = T;
+#if MPC_S0_VARIABLE
       p0 = trial_x0(p0, st[2], alpha); v0k = trial_x0(v0k, st[3], alpha);
+#endif
       /* fp32: the outputs must have been still for two steps in a row (steps are noisy and can be short for other reasons) */
       /* what the polish watches: the step of the outputs (delta_0, a_0), and 0.03 x the largest step of any primal variable
        * -- the predicted trajectory, whose far end is the least determined part of the solution, has then moved by less than

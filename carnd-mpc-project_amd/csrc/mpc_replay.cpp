@@ -8,9 +8,12 @@
  * With --tcp PORT the frames come from ONE TCP connection on 127.0.0.1:PORT instead of stdin (newline-delimited text, not
  * the WebSocket protocol: a relay in front of the simulator would strip that), and the replies go back on the same socket.
  * With --cars B the input is B interleaved connections: line i belongs to car i mod B, and each group of B lines is
- * solved as ONE batch on the device; every car keeps the throttle of its own previous reply, as the reference's
- * handler does in a static (mpc_main.cpp:89-91).  The handler's running mean of its own compute time (:158,:178) is
- * replaced by the constant --extra-latency (default 0) so that a replay is reproducible.
+ * solved as ONE batch on the device; every car keeps the throttle of its own previous reply.  (The reference has ONE
+ * function-local static for that, mpc_main.cpp:89-91, shared by whatever connects: it serves a single simulator.  A value
+ * per car is this tool's generalisation, not parity; with --cars 1 it is the reference's behaviour.)  The replies of a
+ * group are written, in car order, once the whole group has been read: a last group with fewer than B frames is flushed at
+ * end of input (with --tcp: when the peer closes its side).  The handler's running mean of its own compute time
+ * (:158,:178) is replaced by the constant --extra-latency (default 0) so that a replay is reproducible.
  */
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -27,15 +30,18 @@
 #include "mpc_amd.h"
 
 int main(int argc, char **argv) {
-  if (argc < 2) { fprintf(stderr, "usage: mpc_replay <config.json> [--cars B] [--extra-latency s]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: mpc_replay <config.json> [--cars B] [--extra-latency s] [--tcp PORT]\n"); return 2; }
   int64_t cars = 1;
   double extra = 0.0;
   int tcp_port = 0;
-  for (int i = 2; i + 1 < argc; i += 2) {
-    if (!strcmp(argv[i], "--cars")) cars = atoll(argv[i + 1]);
-    else if (!strcmp(argv[i], "--extra-latency")) extra = atof(argv[i + 1]);
-    else if (!strcmp(argv[i], "--tcp")) tcp_port = atoi(argv[i + 1]);
+  for (int i = 2; i < argc; i += 2) {
+    const bool has_value = i + 1 < argc;
+    if (has_value && !strcmp(argv[i], "--cars")) cars = atoll(argv[i + 1]);
+    else if (has_value && !strcmp(argv[i], "--extra-latency")) extra = atof(argv[i + 1]);
+    else if (has_value && !strcmp(argv[i], "--tcp")) tcp_port = atoi(argv[i + 1]);
+    else { fprintf(stderr, "mpc_replay: unknown or incomplete option '%s'\nusage: mpc_replay <config.json> [--cars B] [--extra-latency s] [--tcp PORT]\n", argv[i]); return 2; }
   }
+  if (cars < 1) { fprintf(stderr, "mpc_replay: --cars must be >= 1\n"); return 2; }
   /* frame source / reply sink: stdin/stdout, or one TCP connection */
   int conn = -1;
   std::string pending;

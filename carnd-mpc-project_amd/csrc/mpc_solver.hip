@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     pool_mine = T.pool_bits + (size_t)xcc * (size_t)T.pool_words;
     int got = -1;
     if (threadIdx.x == 0) {
-      for (int w = 0; w < T.pool_words && got < 0; ++w) {
+      for (int w = 0; w < (T.pool_tiles + 63) / 64 && got < 0; ++w) {   /* the tile bits only: the XCD's last two words are its usage record */
         unsigned long long v = __hip_atomic_load(pool_mine + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (v) {
           const int b = __builtin_ctzll(v);
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
       }
     }
     got = __builtin_amdgcn_readfirstlane(got);
+    if (got >= T.pool_tiles) got = -1;       /* (bits beyond the pool are never set; belt and braces) the wave keeps the handle's own tile */
     if (got >= 0 && threadIdx.x == 0) {      /* usage record for mpc_debug_tile_pool: claims, highest tile number + 1 */
       atomicAdd(pool_mine + T.pool_words - 2, 1ull);
       atomicMax(pool_mine + T.pool_words - 1, (unsigned long long)(got + 1));
@@ -485,6 +486,8 @@ struct MpcHandle {
   double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
+  double *d_tel = nullptr;       /* mpc_telemetry_batch_host: device staging, grown on demand */
+  size_t tel_bytes = 0;
   /* last call */
   int64_t last_B = 0;
   bool timed = false;
@@ -626,7 +629,9 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (const char *ep = getenv("MPC_TILE_POOL")) {
     if (atoi(ep) > 0) {
       /* tiles per XCD: its wave slots for this kernel (CUs / 8 XCDs x 4 SIMDs x waves per SIMD) and a margin */
-      const int per_xcd = prop.multiProcessorCount / 8 * 4 * ((f32 && h->occ2) ? 2 : 1);
+      /* (a partition mode that exposes fewer XCDs than 8 only makes the pools larger than needed; a wave that finds its
+       * pool empty keeps the tile of the handle's own workspace) */
+      const int per_xcd = (prop.multiProcessorCount + 7) / 8 * 4 * ((f32 && h->occ2) ? 2 : 1);
       int extra = 16;
       if (const char *ex = getenv("MPC_TILE_POOL_EXTRA")) extra = atoi(ex);
       h->pool = pool_acquire(device, (size_t)h->ws_stride * (f32 ? sizeof(float) : sizeof(double)), per_xcd + (extra > 0 ? extra : 0));
@@ -670,6 +675,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   pool_release(h->pool);
   if (h->d_park) (void)hipFree(h->d_park);
   if (h->d_list) (void)hipFree(h->d_list);
+  if (h->d_tel) (void)hipFree(h->d_tel);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -856,6 +862,45 @@ extern "C" int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, i
   if (h && B > 0 && !cmd) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   return run_impl(h, B, ld, npts, tel, true, extra_latency, ptsx, ptsy, out8, cmd, nullptr, status, nullptr, nullptr, stream_);
 }
+
+/* used by the other translation units of the library (mpc_wire.cpp): the error text of this thread */
+extern "C" void mpc_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }
+
+/* The telemetry handler for host arrays: one copy in, the kernels, one copy out, on the handle's own device and stream
+ * (whatever the caller's current device is), staging kept on the handle.  rows of `tel`, `ptsx`, `ptsy` as in
+ * mpc_telemetry_batch_device with leading dimension ld; the waypoint arrays are inputs only here. */
+extern "C" int mpc_telemetry_batch_host(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
+                                        const double *ptsx, const double *ptsy, double *cmd, int32_t *status) {
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
+  if (npts < 3 || npts > mpc::RUN_MAX_PTS) { g_last_error = "npts must be 3..8"; return MPC_ERR_INVALID; }
+  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (!tel || !ptsx || !ptsy || !cmd || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  MPC_ON_DEVICE(h);
+  const int64_t rows = 6 + 2 * npts, L = (B + 7) / 8 * 8;
+  const size_t need = sizeof(double) * (size_t)((rows + 2) * L) + sizeof(int32_t) * (size_t)L;
+  if (h->tel_bytes < need) {
+    if (h->d_tel) MPC_HIP_CHECK(hipFree(h->d_tel));
+    h->d_tel = nullptr; h->tel_bytes = 0;
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_tel, need));
+    h->tel_bytes = need;
+  }
+  double *d = h->d_tel, *d_cmd = d + rows * L;
+  int32_t *d_st = (int32_t *)(d_cmd + 2 * L);
+  hipStream_t s = h->stream;
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d, sizeof(double) * L, tel, sizeof(double) * ld, sizeof(double) * B, 6, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d + 6 * L, sizeof(double) * L, ptsx, sizeof(double) * ld, sizeof(double) * B, npts, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d + (6 + npts) * L, sizeof(double) * L, ptsy, sizeof(double) * ld, sizeof(double) * B, npts, hipMemcpyHostToDevice, s));
+  const int rc = mpc_telemetry_batch_device(h, B, L, npts, d, extra_latency, d + 6 * L, d + (6 + npts) * L, d_cmd, nullptr, d_st, (void *)s);
+  if (rc != MPC_OK) return rc;
+  MPC_HIP_CHECK(hipMemcpy2DAsync(cmd, sizeof(double) * ld, d_cmd, sizeof(double) * L, sizeof(double) * B, 2, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipStreamSynchronize(s));
+  return MPC_OK;
+}
+
+/* the device a handle lives on (mpc_create's `device`, resolved) */
+extern "C" int mpc_handle_device(const MpcHandle *h) { return h ? h->device : MPC_ERR_INVALID; }
 
 extern "C" int mpc_rollout_batch_device(MpcHandle *h, int64_t B, int64_t ld, int steps, double *state, const double *coeffs,
                                         const double *yaw_lo, const double *yaw_hi, const double *weights, double *hist,

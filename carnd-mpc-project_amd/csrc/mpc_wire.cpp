@@ -126,15 +126,21 @@ extern "C" int64_t mpc_wire_format_manual(char *buf, int64_t cap) {
 }
 
 /* B parsed frames (one per connection) through the device handler.  prev_throttle[i] is the throttle of connection i's
- * previous reply (the reference keeps it in a static, :89-91; 0 before the first message); extra_latency is the mean
- * handler time the reference adds to Config::lookahead (:158).  cmd is [2][B]: steering_angle row, throttle row. */
+ * previous reply -- the reference keeps ONE function-local static for all connections (:89-91; it serves one simulator);
+ * a value per connection is this tool's generalisation to many cars, 0 before a car's first message -- and extra_latency
+ * is the mean handler time the reference adds to Config::lookahead (:158).  cmd is [2][B]: steering_angle row, throttle
+ * row.  Runs on the handle's own device and stream (mpc_telemetry_batch_host), whatever the caller's current device. */
+extern "C" void mpc_internal_set_error(const char *msg);
 extern "C" int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcWireTelemetry *tel, const double *prev_throttle,
                                              double extra_latency, double *cmd, int32_t *status) {
-  if (!h || B < 0 || (B > 0 && (!tel || !cmd || !status))) return MPC_ERR_INVALID;
+  if (!h || B < 0 || (B > 0 && (!tel || !cmd || !status))) { mpc_internal_set_error("mpc_wire_telemetry_batch_host: NULL argument or B < 0"); return MPC_ERR_INVALID; }
   if (B == 0) return MPC_OK;
   const int npts = tel[0].npts;
   for (int64_t i = 0; i < B; i++)
-    if (tel[i].npts != npts) return MPC_ERR_INVALID;          /* one waypoint count per batch (the simulator always sends 6) */
+    if (tel[i].npts != npts) {          /* one waypoint count per batch (the simulator always sends 6) */
+      mpc_internal_set_error("mpc_wire_telemetry_batch_host: the frames of one batch must carry the same number of waypoints");
+      return MPC_ERR_INVALID;
+    }
   const int64_t rows = 6 + 2 * npts;
   std::vector<double> host((size_t)(rows * B));
   for (int64_t i = 0; i < B; i++) {
@@ -143,25 +149,5 @@ extern "C" int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcW
     host[4 * B + i] = t.steering_angle; host[5 * B + i] = prev_throttle ? prev_throttle[i] : 0.0;
     for (int q = 0; q < npts; q++) { host[(6 + q) * B + i] = t.ptsx[q]; host[(6 + npts + q) * B + i] = t.ptsy[q]; }
   }
-  int dev_prev = -1;
-  (void)hipGetDevice(&dev_prev);
-  double *d = nullptr;
-  int32_t *ds = nullptr;
-  int rc = MPC_ERR_HIP;
-  do {
-    if (hipMalloc((void **)&d, sizeof(double) * (size_t)((rows + 2) * B)) != hipSuccess) break;
-    if (hipMalloc((void **)&ds, sizeof(int32_t) * (size_t)B) != hipSuccess) break;
-    if (hipMemcpy(d, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice) != hipSuccess) break;
-    double *d_cmd = d + rows * B;
-    rc = mpc_telemetry_batch_device(h, B, B, npts, d, extra_latency, d + 6 * B, d + (6 + npts) * B, d_cmd, nullptr, ds, nullptr);
-    if (rc != MPC_OK) break;
-    rc = MPC_ERR_HIP;
-    if (hipDeviceSynchronize() != hipSuccess) break;
-    if (hipMemcpy(cmd, d_cmd, sizeof(double) * 2 * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) break;
-    if (hipMemcpy(status, ds, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) break;
-    rc = MPC_OK;
-  } while (0);
-  if (d) (void)hipFree(d);
-  if (ds) (void)hipFree(ds);
-  return rc;
+  return mpc_telemetry_batch_host(h, B, B, npts, host.data(), extra_latency, host.data() + 6 * B, host.data() + (6 + npts) * B, cmd, status);
 }

@@ -167,6 +167,7 @@ int mpc_set_params(MpcHandle *h, const MpcParams *p);
 void mpc_destroy(MpcHandle *h);
 const char *mpc_last_error(void);
 int mpc_abi_version(void);
+int mpc_handle_device(const MpcHandle *h);   /* the device the handle's memory and launches live on */
 
 /* ---- the hot path ---------------------------------------------------------- */
 /*
@@ -227,6 +228,10 @@ int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const do
  *   out8 [8][ld] or NULL   run()'s own return vector */
 int mpc_telemetry_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
                                double *ptsx, double *ptsy, double *cmd, double *out8, int32_t *status, void *stream);
+/* The same for host arrays (tel, ptsx, ptsy read only; cmd [2][ld], status [ld] written): one copy in, the kernels, one copy
+ * out, on the handle's own device and stream whatever the caller's current device is; synchronises. */
+int mpc_telemetry_batch_host(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *tel, double extra_latency,
+                             const double *ptsx, const double *ptsy, double *cmd, int32_t *status);
 /* Closed-loop rollout (the pattern of src/test.cpp:79-111): `steps` times
  * solve() and feed {x1,y1,psi1,v1,cte1,epsi1} back as the next state, cold start each time as the reference does.
  *   state [6][ld]          in: start states; out: the state after the last step

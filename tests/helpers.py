@@ -166,3 +166,35 @@ def garbage_batch(batch, weights):
     for i, (_, fn) in enumerate(defects):
         fn(i)
     return b, w, [d[0] for d in defects]
+
+
+def closed_loop_report(hist, step_status, ref_hist, ref_status):
+    """Closed loops (src/test.cpp:79-111) of two solvers side by side: hist [steps, 9, cars] and the status of every solve
+    [steps, cars] of each.  EVERY solve is counted.  A car is "comparable" up to and including its first solve that either
+    solver did not converge on (what comes back from a failed solve is fed into the next one) and up to its first solve on
+    which both converge to different local minima (|d delta0| > 1e-3 with both SUCCESS: the NLP is non-convex, and late in
+    a loop the car is far beyond the stretch of road the polynomial was fitted on)."""
+    steps, _, cars = hist.shape
+    d = np.abs(hist - ref_hist)
+    d_steer, d_acc, d_state = d[:, 6], d[:, 7], d[:, :6].max(1)
+    bad = (step_status != 0) | (ref_status != 0)
+    after_failure = (np.cumsum(bad, axis=0) - bad) > 0                      # strictly after the first failed solve of the car
+    both_ok = ~bad & ~after_failure
+    branch = both_ok & (d_steer > 1e-3)
+    after_branch = np.cumsum(branch, axis=0) > 0                            # the diverging solve and everything behind it
+    comparable = both_ok & ~after_branch
+    nan0 = lambda x: np.where(np.isfinite(x), x, 1e300)
+    q = lambda x: [float(np.quantile(nan0(x), p)) for p in (0.5, 0.99, 0.999, 1.0)]
+    allv = ~after_failure & ~bad                                            # all solves with the same kind of input on both sides
+    cm = lambda x: float(x[comparable].max()) if comparable.any() else 0.0
+    return {"cars": int(cars), "steps": int(steps), "solves_compared": int(steps * cars),
+            "status_differs": int(((step_status != ref_status) & ~after_failure).sum()),
+            "status_counts": np.bincount(step_status.ravel().astype(np.int64), minlength=5).tolist(),
+            "ref_status_counts": np.bincount(ref_status.ravel().astype(np.int64), minlength=5).tolist(),
+            "solves_behind_a_failed_solve": int(after_failure.sum()),
+            "cars_on_another_local_minimum": int(after_branch.any(0).sum()), "solves_behind_such_a_fork": int(after_branch.sum()),
+            "cars_that_start_a_solve_on_a_yaw_bound": None,
+            "quantiles": "p50, p99, p99.9, max over every solve both solvers converged on (forked cars included)",
+            "d_steer_rad": q(d_steer[allv]), "d_accel": q(d_acc[allv]), "d_state": q(d_state[allv]),
+            "comparable_solves": int(comparable.sum()),
+            "comparable_max": {"d_steer_rad": cm(d_steer), "d_accel": cm(d_acc), "d_state": cm(d_state)}}

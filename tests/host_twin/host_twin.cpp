@@ -7,6 +7,7 @@
  * never linked into the product library and nothing in the product path
  * loads it: the shipped path is HIP only and fails loudly without a device.
  */
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>

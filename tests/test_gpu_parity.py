@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from helpers import TEST_CPP, assert_parity, load_golden, oracle_solve_batch, twin_solve
+from helpers import TEST_CPP, TOL_STEER, assert_parity, load_golden, oracle_solve_batch, twin_solve
 
 pytestmark = pytest.mark.gpu
 
@@ -98,6 +98,29 @@ def test_long_horizon_matches_oracle(pkg, golden_dir, waypoints, torch_dev):
     # stated 1e-6 holds for a0 too -- interior a0 included, which IPOPT's own stopping rule leaves ~1e-4 loose
     assert_parity(r["out"][:, ::4], ref["out"], r["traj"][:, ::4], ref["traj"], "N=25")
     assert (ref["status"] == 0).all()
+
+
+def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torch_dev):
+    """polish = 0 in both solvers: IPOPT's own rule (stop at the FIRST iterate with E_0 <= tol) stays exercised on the hardware.
+    Two correct solvers that stop one iterate apart then differ by what a last Newton step moves: the stated 1e-6 holds for
+    delta0, a weakly determined interior a0 gets the 1e-4 of round 1.  Parity below the resolution of
+    the reference's figures is unpinned either way: no IPOPT output to six digits exists."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    params.polish = 0
+    B = 1024
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=48)
+    r = gpu_solve(pkg, params, b, torch_dev)
+    assert (r["status"] == 0).all()
+    idx = list(range(0, B, 8))
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, idx, opt=O.default_options(polish=0))
+    assert (ref["status"] == 0).all()
+    assert np.max(np.abs(r["out"][6, idx] - ref["out"][6])) <= TOL_STEER
+    assert np.max(np.abs(r["out"][7, idx] - ref["out"][7])) <= 1e-4
+    assert np.max(np.abs(r["out"][:6, idx] - ref["out"][:6])) <= 1e-4
+    # and the polish costs iterations: the default solve of the same batch takes more of them
+    pol = params.copy(); pol.polish = 1
+    rp = gpu_solve(pkg, pol, b, torch_dev)
+    assert 0.2 < rp["iters"].mean() - r["iters"].mean() < 1.0
 
 
 def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev):
@@ -232,7 +255,9 @@ def test_full_size_properties(pkg, host_twin, golden_dir, waypoints, torch_dev):
     f0 = cf[0]; fp0 = cf[1]                                     # x0 = 0
     assert np.max(np.abs(out[0] - v0 * dt)) < 1e-8              # x1 = x0 + cos(0) v0 dt
     assert np.max(np.abs(out[1])) < 1e-8                        # y1 = y0 + sin(0) v0 dt
-    assert np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-8
+    # (1e-7: the returned psi1 / delta0 are projected into the caller's bounds from a point solved inside bounds relaxed by
+    # 1e-8 max(1, |b|) -- IPOPT's bound_relax_factor and honor_original_bounds)
+    assert np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-7
     assert np.max(np.abs(out[3] - (v0 + out[7] * dt))) < 1e-8
     assert np.max(np.abs(out[4] - (f0 + np.sin(s0[5]) * v0 * dt))) < 1e-8
     assert np.max(np.abs(out[5] - (out[2] - np.arctan(fp0)))) < 1e-8
@@ -272,7 +297,7 @@ def test_full_size_properties_config3_shard(pkg, golden_dir, waypoints, torch_de
     out, s0, cf = r["out"], b["state"], b["coeffs"]
     dt, Lf, v0 = params.dt, params.Lf, b["state"][3]
     assert np.all(out[2] >= b["yaw_lo"] - 1e-9) and np.all(out[2] <= b["yaw_hi"] + 1e-9) and np.all(np.abs(out[6]) <= params.max_steering + 1e-9)
-    assert np.max(np.abs(out[0] - v0 * dt)) < 1e-8 and np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-8
+    assert np.max(np.abs(out[0] - v0 * dt)) < 1e-8 and np.max(np.abs(out[2] - out[6] * v0 * dt / Lf)) < 1e-7   # projected into the bounds
     assert np.max(np.abs(out[3] - (v0 + out[7] * dt))) < 1e-8 and np.max(np.abs(out[4] - (cf[0] + np.sin(s0[5]) * v0 * dt))) < 1e-8
     assert np.max(np.abs(r["traj"][1] - out[0])) == 0 and r["traj"].shape == (50, B)
     idx = [int(i) for i in np.random.default_rng(5).choice(B, 48, replace=False)]

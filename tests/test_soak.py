@@ -1,6 +1,7 @@
 """Soak: whole batches on the device against the ORACLE, every instance (not a sample), the oracle spread over the host's
-cores.  Opt-in (MPC_SOAK=1: it needs a minute of 16 cores); the report goes to gpurun_out/soak.json and is kept under
-profiles/.  Sizes: MPC_SOAK_SCALE (default 1.0) times 65 536 headline / 32 768 weight-sweep / 8 192 long-horizon instances."""
+cores.  Part of the default `-m gpu` run at 1/8 scale (8 192 headline + 4 096 weight-sweep + 1 024 long-horizon instances,
+8 192 fp32, 2 048 run() poses, 256 closed loops of 25 solves: about a minute of 14 cores); MPC_SOAK=1 runs the full sizes
+(65 536 / 32 768 / 8 192 ...), MPC_SOAK_SCALE overrides the factor.  Reports go to gpurun_out/ and are kept under profiles/."""
 import json
 import multiprocessing as mp
 import os
@@ -10,9 +11,21 @@ import pytest
 
 import oracle_lib as O
 from helpers import (F32_TOL_ACCEL, F32_TOL_COST_REL, F32_TOL_STATE, F32_TOL_STEER, F32_TOL_TRAJ, TOL_ACCEL, TOL_COST_REL, TOL_STEER,
-                     TOL_TRAJ)
+                     TOL_TRAJ, closed_loop_report)
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("MPC_SOAK"), reason="opt-in: MPC_SOAK=1")]
+pytestmark = [pytest.mark.gpu]
+
+
+def _scale():
+    return float(os.environ.get("MPC_SOAK_SCALE", "1.0" if os.environ.get("MPC_SOAK") else "0.125"))
+
+
+def _workers():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 2
+    return max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), cores - 1))
 
 
 def _oracle_all(config, over, b, w, workers):
@@ -30,8 +43,7 @@ def _oracle_all(config, over, b, w, workers):
 def test_soak_whole_batches_against_the_oracle(pkg, golden_dir, waypoints):
     import torch
     dev = torch.device("cuda:0")
-    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
-    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    scale, workers = _scale(), _workers()
     report = {"what": "device (mpc_solve_batch_device, fp64, default parameters) against oracle/mpc_oracle.c on EVERY instance of a batch", "workers": workers, "workloads": []}
     for name, config, over, B, sweep, seed in (("headline (configs[2])", "config-fast.json", {}, int(65536 * scale), False, 101),
                                                ("weight sweep", "config-fast.json", {}, int(32768 * scale), True, 102),
@@ -68,8 +80,7 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
     the fp64 oracle, stated fp32 tolerances (helpers.F32_TOL_*), every status accounted for."""
     import torch
     dev = torch.device("cuda:0")
-    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
-    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    scale, workers = _scale(), _workers()
     B = int(65536 * scale)
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
     params.precision = pkg.PRECISION_F32
@@ -108,8 +119,7 @@ def test_soak_run_and_closed_loop_against_the_oracle(pkg, golden_dir, waypoints)
     (src/test.cpp:79-111) for 2 048 cars, every instance against the oracle doing the same."""
     import torch
     dev = torch.device("cuda:0")
-    scale = float(os.environ.get("MPC_SOAK_SCALE", "1.0"))
-    workers = max(1, min(int(os.environ.get("MPC_SOAK_WORKERS", "14")), (os.cpu_count() or 2) - 1))
+    scale, workers = _scale(), _workers()
     cfgname = "config-fast.json"
     params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
@@ -143,32 +153,29 @@ def test_soak_run_and_closed_loop_against_the_oracle(pkg, golden_dir, waypoints)
     with mp.get_context("spawn").Pool(workers) as pool:
         parts = pool.map(O.rollout_chunk_full, [(cfgname, {}, c(sc["state"][:, lo:hi]), c(sc["coeffs"][:, lo:hi]), c(sc["yaw_lo"][lo:hi]), c(sc["yaw_hi"][lo:hi]), steps)
                                                for lo, hi in _chunks(B, workers)])
-    worst = np.concatenate([p[0] for p in parts]); oh = np.concatenate([p[1] for p in parts], axis=2)
-    # A car whose heading has reached a yaw bound (they are fixed for the whole loop while the road turns: the reference's
-    # own 30-01-2.png shows it) starts its next solve ON the bound, 1e-12 inside: a problem whose answer is decided by the
-    # last bits of the previous one.  From there on the two solvers are no longer solving the same problem; the comparison
-    # covers every car up to the step at which its heading first comes within 1e-6 of a bound.
-    psi_d = np.concatenate([sc["state"][2][None], hist[:, 2]]); psi_o = np.concatenate([sc["state"][2][None], oh[:, 2]])
-    marg = np.minimum(np.minimum(sc["yaw_hi"] - psi_d, psi_d - sc["yaw_lo"]), np.minimum(sc["yaw_hi"] - psi_o, psi_o - sc["yaw_lo"]))   # [steps+1, B]
-    on_bound = marg < 1e-6
-    first = np.where(on_bound.any(0), on_bound.argmax(0), steps + 1)      # hist[t] is comparable while t < first (its start state was clear)
-    valid = np.arange(steps)[:, None] < first[None, :]
-    free = first > steps                                                   # cars that never touch a bound
-    same = (status == 0) == (worst == 0)
-    d = np.abs(hist - oh)
-    pick = lambda rows: (d[:, rows].max(1) if isinstance(rows, slice) else d[:, rows])[valid]
-    q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.999, 1.0)]
-    report["closed_loop"] = {"cars": B, "steps": steps, "solves": B * steps, "cars_never_on_a_yaw_bound": int(free.sum()),
-                             "solves_compared": int(valid.sum()), "status_class_differs_among_free_cars": int((~same & free).sum()),
-                             "device_status_counts": np.bincount(status, minlength=5).tolist(), "oracle_status_counts": np.bincount(worst, minlength=5).tolist(),
-                             "quantiles": "p50, p99, p99.9, max over the compared solves", "d_steer_rad": q(pick(6)), "d_accel": q(pick(7)), "d_state": q(pick(slice(0, 6)))}
-    print(json.dumps(report["closed_loop"]))
+    oh = np.concatenate([p[1] for p in parts], axis=2); ost = np.concatenate([p[2] for p in parts], axis=1)
+    # EVERY solve of every car is compared (round 2 masked everything after a car's first contact with a yaw bound: with
+    # IPOPT's bound relaxation restated in both solvers a solve that starts on a bound is an ordinary problem).
+    # the status of every single solve: the same loop as repeated calls of the solve entry point (bitwise the rollout's history)
+    step_status = np.zeros((steps, B), dtype=np.int32)
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        st_t = t(sc["state"])
+        for k in range(steps):
+            r = mpc.solve_torch(st_t, t(sc["coeffs"]), t(sc["yaw_lo"]), t(sc["yaw_hi"]))
+            torch.cuda.synchronize()
+            step_status[k] = r["status"].cpu().numpy()
+            assert np.array_equal(r["out"].cpu().numpy(), hist[k], equal_nan=True), k
+            st_t = r["out"][:6].contiguous()
+    assert np.array_equal(step_status.max(0), status)
+    cl = closed_loop_report(hist, step_status, oh, ost)
+    report["closed_loop"] = cl
+    print(json.dumps(cl))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/soak_8f.json", "w"), indent=1)
-    cl = report["closed_loop"]
-    assert cl["status_class_differs_among_free_cars"] == 0
-    assert cl["solves_compared"] > 0.4 * B * steps and cl["cars_never_on_a_yaw_bound"] > B // 8
-    # Closed loop: what one solve leaves (<= 1e-6) is fed back up to 25 times and the loop's own dynamics act on it, so the
-    # single-solve tolerances hold for 99.9 % of the compared solves and the worst one is within 50x of them.
-    assert cl["d_steer_rad"][2] <= 2 * TOL_STEER and cl["d_accel"][2] <= 2 * TOL_ACCEL and cl["d_state"][2] <= 2 * TOL_TRAJ, cl
-    assert cl["d_steer_rad"][3] <= 50 * TOL_STEER and cl["d_accel"][3] <= 50 * TOL_ACCEL and cl["d_state"][3] <= 50 * TOL_TRAJ, cl
+    assert cl["solves_compared"] == B * steps
+    assert cl["status_differs"] <= max(1, B * steps // 10000), cl                 # the one-in-51 200 class: a solve on the rounding floor of tol
+    assert cl["cars_on_another_local_minimum"] <= max(1, B // 250), cl            # both converged, different basins (off-road states late in a loop)
+    # single-solve tolerances at the 99.9 % quantile over ALL solves (diverged cars included); what a solve leaves is fed
+    # back up to 25 times, so the worst comparable one may be 50x that
+    assert cl["d_steer_rad"][2] <= TOL_STEER and cl["d_accel"][2] <= TOL_ACCEL and cl["d_state"][2] <= TOL_TRAJ, cl
+    assert cl["comparable_max"]["d_steer_rad"] <= 50 * TOL_STEER and cl["comparable_max"]["d_accel"] <= 50 * TOL_ACCEL and cl["comparable_max"]["d_state"] <= 50 * TOL_TRAJ, cl
