@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
 KFLOP_PER_STAGE_ITER = 2.5
+DEFAULT_TAIL_CUT = 0                                           # passes after which an instance leaves its launch (0: tails not deferred)
 
 
 def parse_args(argv=None):
@@ -77,6 +78,22 @@ def parse_args(argv=None):
     ap.add_argument("--pass-cuts", default="", help="multi-phase solve (MpcParams.pass_cut, pass_cut_next): up to four comma-separated "
                     "cuts, e.g. 16,16,32 -- instances still running after that many passes are re-packed into dense waves for "
                     "a further launch; bitwise the same results (measured: no gain in time per batch, DESIGN.md 6c)")
+    ap.add_argument("--tail-cut", type=int, default=-1, help="deferred tails (MpcParams.tail_cut): instances still running after this many "
+                    "passes leave their launch and are finished by the handle's tail launches while later batches run; every batch is "
+                    "final (tails included) inside the timed region.  0 = off; default: on (see DEFAULT_TAIL_CUT)")
+    ap.add_argument("--tail-ring", type=int, default=32, help="batches whose tails may be outstanding per handle")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (the unfiltered population of the "
+                    "headline workload and the other BASELINE.json configs)")
+    ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of an extra leg that does not set its own")
+    ap.add_argument("--no-leg-tails", dest="leg_tails", action="store_false", help="run the extra legs without deferred tails")
+    ap.add_argument("--population", choices=("filtered", "survey", "unfiltered"), default="filtered",
+                    help="instance generator: 'filtered' redraws what the reference's road model does not hold for (scenarios.py); "
+                         "'survey' applies only SURVEY.md section 8d's rejection (compensated speed above Config::maxSpeed); "
+                         "'unfiltered' keeps every draw with a finite fit")
+    ap.add_argument("--gather", choices=("root", "all"), default="root", help="the batch's one collective: gather to rank 0 (default; what "
+                    "north_star asks for) or all_gather_into_tensor to every rank")
+    ap.add_argument("--gather-results-only", action="store_true", help="trajectories are computed but stay on their rank: only out[9], status, "
+                    "iters travel")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
     ap.add_argument("--no-priority-stream", action="store_true", help="run the solves on a normal-priority stream")
     ap.add_argument("--force-collective", action="store_true", help="one rank only: initialise RCCL with world size 1 and run the per-batch "
@@ -87,6 +104,10 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.inflight <= 0:
         args.inflight = 4 if args.precision == "f32" else 2
+    if args.unfiltered:
+        args.population = "unfiltered"
+    if args.tail_cut < 0:
+        args.tail_cut = 0 if args.stub else DEFAULT_TAIL_CUT
     return args
 
 
@@ -164,6 +185,173 @@ def cpu_baseline_legs(args, batch, w_np, over, status, out_np, budget):
     return one, allc, worst_steer, worst_acc, n_done
 
 
+class _NullCtx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+class Pipeline:
+    """One workload kept `nfl` batches in flight the way a serving loop would run it: `nfl` handles on `nfl` streams, results
+    written straight into the packed buffers of sharding.PackedGather, the path's one collective issued per batch.  With
+    deferred tails (tail_cut > 0) a batch's stragglers are finished by its handle's tail launches while later batches run;
+    the batch is gathered -- on a stream of its own, behind the tail's event -- once it is final, and drain() completes
+    everything that is outstanding (the timed region ends after drain())."""
+
+    def __init__(self, pkg, torch, params, B, tensors, d_w, want_traj, nfl, dev, local_rank, dist, args, stub=None, tail_cut=0, tail_ring=16):
+        self.torch, self.pkg, self.B, self.nfl, self.dev, self.stub = torch, pkg, B, max(1, nfl), dev, stub
+        self.tensors, self.d_w = tensors, d_w
+        self.tail = int(tail_cut) if stub is None else 0
+        p = params.copy()
+        p.tail_cut = self.tail
+        p.tail_ring = int(tail_ring)
+        self.params = p
+        make = (lambda: stub.BatchedMPC(p, B)) if stub else (lambda: pkg.BatchedMPC(p, B, device=local_rank))
+        self.mpcs = [make() for _ in range(self.nfl)]
+        self.ring = int(tail_ring) if self.tail else 0
+        # buffer sets: one per batch that may be outstanding (in flight, or waiting for its tail and its gather)
+        n_slots = max(2, self.nfl) if not self.tail else self.nfl * (self.ring + 1)
+        tdt = torch.float32 if p.precision == pkg.PRECISION_F32 else torch.float64
+        self.pg = pkg.sharding.PackedGather(B, p.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
+                                            slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather == "root", gather_traj=not args.gather_results_only)
+        self.streams, self.gstream = None, None
+        if stub is None:
+            torch.cuda.synchronize(dev)
+            # The solves run on high-priority streams: when a batch's gather (RCCL's own stream, normal priority) and the next
+            # batch's solve become ready together, the solve's waves are placed first.
+            self.streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(self.nfl)]
+            self.gstream = torch.cuda.Stream(device=dev)
+        self.nstep = 0
+        self.owner = [None] * n_slots           # (handle, batch id) whose results sit in the slot
+        self.waiting = []                       # batches issued, not yet handed to the gather: (slot, handle, batch id)
+        self.lag = self.nfl * max(1, self.ring - 2)
+
+    def _ctx(self, stream):
+        return self.torch.cuda.stream(stream) if self.stub is None else _NullCtx()
+
+    def _gather(self, slot, h, bid):
+        with self._ctx(self.gstream):
+            h.tail_stream_wait(bid, self.gstream)          # the batch is final: its own launch and the tail launch that served it
+            self.pg.start(slot)
+
+    def step(self, ev=None):
+        slot = self.nstep % self.pg.slots
+        j = self.nstep % self.nfl
+        h = self.mpcs[j]
+        st = self.streams[j] if self.streams else None
+        with self._ctx(st):
+            self.pg.wait(slot)                              # the gather that last read this buffer set has finished
+            if self.tail and self.owner[slot] is not None:  # ... and so has the tail that last wrote it
+                self.owner[slot][0].tail_stream_wait(self.owner[slot][1], st)
+            if ev is not None:
+                ev[0].record()
+            h.solve_torch(*self.tensors, weights=self.d_w, outputs=self.pg.outputs(slot))   # async on this stream
+            if ev is not None:
+                ev[1].record()
+            if not self.tail:
+                self.pg.start(slot)                         # the path's only collective
+        if self.tail:
+            bid = h.last_batch_id()
+            self.owner[slot] = (h, bid)
+            self.waiting.append((slot, h, bid))
+            while len(self.waiting) > self.lag:
+                self._gather(*self.waiting.pop(0))
+        self.nstep += 1
+
+    def drain(self):
+        while self.waiting:
+            self._gather(*self.waiting.pop(0))
+        if self.tail:
+            for h in self.mpcs:
+                h.tail_wait(0)
+        self.pg.finish()
+
+    def last_slot(self):
+        return (self.nstep - 1) % self.pg.slots
+
+    def close(self):
+        for h in self.mpcs:
+            h.close()
+
+
+def timed_run(torch, pipe, steps, warmup, sync_all, with_events):
+    for _ in range(warmup):
+        pipe.step()
+    pipe.drain()
+    sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if with_events else None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.step(ev[i] if ev else None)
+    pipe.drain()
+    sync_all()
+    return time.perf_counter() - t0, ev
+
+
+def summarize(pkg, np, pipe, B, steps, elapsed):
+    outs = pipe.pg.outputs(pipe.last_slot())
+    status = outs["status"].cpu().numpy()
+    iters = outs["iters"].cpu().numpy()
+    r = {"solves_per_s": B * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "batch": B, "steps": steps,
+         "batches_in_flight": pipe.nfl, "tail_cut": pipe.tail,
+         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(6)},
+         "mean_iterations": float(iters.mean()), "max_iterations": int(iters.max())}
+    if pipe.tail and pipe.stub is None:
+        info = [h.tail_info() for h in pipe.mpcs]
+        r["tails"] = {"tail_launches": sum(i["tail_launches"] for i in info), "batches_deferred": sum(i["batches_deferred"] for i in info),
+                      "ring": info[0]["ring"], "capacity_per_batch": info[0]["capacity_per_batch"],
+                      "waves_per_tail_launch": info[0]["waves_per_tail_launch"], "tail_stream_high_priority": info[0]["tail_stream_high_priority"], "tail_streams_per_handle": info[0]["tail_streams"],
+                      "instances_over_the_cut_in_the_last_batch": int((iters + 2 > pipe.tail).sum())}
+    return r, status, iters, outs
+
+
+def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
+    """The other populations the driver-timed line reports: the headline workload drawn with SURVEY.md
+    8d's own rejection only, and BASELINE.json configs[1], [3] (one GPU's share) and [4] (one GPU's share).  A few steps each."""
+    legs = {}
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+
+    def leg(name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered", velocity_weights=(0.0, 1.0, 100.0), note=None,
+            tail_cut=0, steps=None):
+        params = pkg.params_from_json(os.path.join(golden, config), **over)
+        if f32:
+            params.precision = pkg.PRECISION_F32
+        if args.max_iter > 0:
+            params.max_iter = args.max_iter
+        tdt = torch.float32 if f32 else torch.float64
+        if kind == "straight":
+            b = pkg.scenarios.straight_line_batch(B, params)
+            b["drawn"], b["rejected"] = B, {}
+        else:
+            b = pkg.scenarios.lake_track_batch(B, params, wp, stream=3, filtered={"filtered": True, "survey": "survey", "unfiltered": False}[population])
+        w = pkg.scenarios.weight_sweep(B, params, seed=1234, velocity_weights=velocity_weights) if sweep else None
+        tens = (t(b["state"], tdt), t(b["coeffs"], tdt), t(b["yaw_lo"], tdt), t(b["yaw_hi"], tdt))
+        steps = steps or args.leg_steps
+        pipe = Pipeline(pkg, torch, params, B, tens, t(w, tdt) if w is not None else None, want_traj, nfl, dev, local_rank, None, args,
+                        tail_cut=tail_cut if args.leg_tails else 0, tail_ring=64)
+        elapsed, _ = timed_run(torch, pipe, steps, 2, sync_all, False)
+        r, _, _, _ = summarize(pkg, np, pipe, B, steps, elapsed)
+        pipe.close()
+        r.update({"workload": name, "config": config, "N": params.N, "dt": params.dt, "dtype": "f32" if f32 else "f64", "trajectories": want_traj,
+                  "population": population, "draws": int(b["drawn"]), "rejected": b["rejected"]})
+        if note:
+            r["note"] = note
+        return r
+
+    legs["unfiltered"] = leg("the headline workload (configs[2]) drawn with SURVEY.md 8d's rejection only (compensated speed above Config::maxSpeed)",
+                             "config-fast.json", {}, 65536, "lake", False, False, True, 2, population="survey", tail_cut=20, steps=300 if args.leg_tails else 10,
+                             note="28 of the 65 536 instances need 100-400 iterations (9 end at the iteration cap, 19-20 with a failed line search, in the "
+                                  "oracle as on the device): their serial chains last 70-100 ms.  Deferred tails (tail_cut 20) take them out of the launches; "
+                                  "every batch, stragglers included, is final inside the timed region (the drain of the last tails is part of it)")
+    legs["configs_1"] = leg("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json", "config-stable.json", {}, 4096, "straight",
+                            False, False, True, 2)
+    legs["configs_3_share"] = leg("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",
+                                  "config-stable.json", dict(N=25, dt=0.05), 32768, "lake", False, False, True, 4, tail_cut=24, steps=40)
+    legs["configs_4_share"] = leg("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, "
+                                  "per-instance weight sweep (epsi / v incl. 0 / delta / a)", "config-fast.json", {}, 131072, "lake", True, True, False,
+                                  4, tail_cut=24, steps=60)
+    return legs
+
+
 def main():
     args = parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,9 +363,11 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    # HIP serves 4 hardware queues per process by default; more batches in flight than that need more (read at HIP start-up)
-    if args.inflight > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.inflight, 8)))
+    # HIP serves 4 hardware queues per process by default; more streams in use than that need more (read at HIP start-up):
+    # batches in flight, their tail streams, the gather stream, and the heavy-tailed legs of the default run
+    want_q = args.inflight * (2 if args.tail_cut else 1) + 1
+    if want_q > 4 or (not args.no_legs and world_env == 1 and not args.stub):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import numpy as np
     import torch
@@ -241,21 +431,18 @@ def main():
         B = args.batch
     want_traj = not args.no_traj
     # every rank draws its own instances (rank-specific PRNG stream)
-    batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank, filtered=not args.unfiltered)
+    batch = pkg.scenarios.lake_track_batch(B, params, wp, stream=3 + 16 * rank,
+                                           filtered={"filtered": True, "survey": "survey", "unfiltered": False}[args.population])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=tdt)
-    d_state, d_coef, d_ylo, d_yhi = t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"])
-    w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank) if args.weights_sweep else None
+    tensors = (t(batch["state"]), t(batch["coeffs"]), t(batch["yaw_lo"]), t(batch["yaw_hi"]))
+    w_np = pkg.scenarios.weight_sweep(B, params, seed=1234 + rank, velocity_weights=(0.0, 1.0, 100.0)) if args.weights_sweep else None
     d_w = t(w_np) if w_np is not None else None
     # Batches in flight: a launch of 65 536 instances is exactly one wave per SIMD and lasts as long as its slowest wave
-    # (25 iterations) while the average wave is done after ~70 % of that time; a second handle on a second stream lets
-    # the next batch's waves take the SIMDs as they become free (measured: 2.2 -> 1.5 ms per batch).
-    nfl = max(1, args.inflight)
-    make = (lambda: stub.BatchedMPC(params, B)) if stub else (lambda: pkg.BatchedMPC(params, B, device=local_rank))
-    mpcs = [make() for _ in range(nfl)]
-    # results go straight into a packed buffer that is gathered with one all_gather_into_tensor; two buffer sets
-    # alternate so that the gather of batch i overlaps the solve of batch i+1 (sharding.PackedGather)
-    pg = pkg.sharding.PackedGather(B, params.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
-                                   slots=max(2, nfl), dtype=tdt, force=args.force_collective)
+    # while the average wave is done after ~70 % of that time; a second handle on a second stream lets the next batch's
+    # waves take the SIMDs as they become free (measured: 2.2 -> 1.3 ms per batch).
+    pipe = Pipeline(pkg, torch, params, B, tensors, d_w, want_traj, args.inflight, dev, local_rank, dist, args, stub=stub,
+                    tail_cut=args.tail_cut, tail_ring=args.tail_ring)
+    nfl, pg = pipe.nfl, pipe.pg
 
     def sync_all():
         if stub is None:
@@ -265,75 +452,40 @@ def main():
             if stub is None:
                 torch.cuda.synchronize(dev)
 
-    nstep = 0
-
-    class _NullCtx:
-        def __enter__(self): return self
-        def __exit__(self, *a): return False
-
-    def step(ev=None):
-        nonlocal nstep
-        slot = nstep % pg.slots
-        h = mpcs[nstep % nfl]
-        with (torch.cuda.stream(streams[nstep % nfl]) if stub is None else _NullCtx()):
-            pg.wait(slot)                               # the gather that last read this buffer set has finished
-            if ev is not None:
-                ev[0].record()
-            h.solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(slot))   # async on this stream
-            if ev is not None:
-                ev[1].record()
-            pg.start(slot)                              # the path's only collective
-        nstep += 1
-
-    # The solves run on a high-priority stream: when a batch's gather (RCCL's own stream, normal priority) and the next
-    # batch's solve become ready together, the solve's 1 024 waves are placed first and the collective's workgroups take
-    # the SIMDs the solve frees in its tail, instead of holding SIMDs that 512-register waves cannot share.
-    streams = None
-    if stub is None:
-        torch.cuda.synchronize(dev)
-        streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(nfl)]
-    for _ in range(args.warmup):
-        step()
-    pg.finish()
-    sync_all()
     # HIP events on the stream the kernel is launched on: torch's current stream, whose handle is what
     # solve_torch passes to mpc_solve_batch_device (a NULL handle is HIP's null stream = torch's default)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if stub is None else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ev[i] if ev else None)
-    pg.finish()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed, ev = timed_run(torch, pipe, args.steps, args.warmup, sync_all, stub is None)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev] if ev else [1e3 * elapsed / args.steps]
     kernel_ms_avg = float(np.mean(kernel_ms))
-    stats = mpcs[(nstep - 1) % nfl].stats()
-    last = (nstep - 1) % pg.slots
+    summary, status, iters_np, outs = summarize(pkg, np, pipe, B, args.steps, elapsed)
+    out_np = outs["out"].cpu().numpy()
+    last = pipe.last_slot()
     # the same launch alone on the device (nothing else in flight), for reference
     iso = []
     if stub is None:
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(streams[0]):
-                e0.record(); mpcs[0].solve_torch(d_state, d_coef, d_ylo, d_yhi, weights=d_w, outputs=pg.outputs(0)); e1.record()
+            with torch.cuda.stream(pipe.streams[0]):
+                e0.record(); pipe.mpcs[0].solve_torch(*tensors, weights=d_w, outputs=pg.outputs(0)); e1.record()
+            pipe.mpcs[0].tail_wait(0)
             torch.cuda.synchronize(dev)
             iso.append(e0.elapsed_time(e1))
-    outs = pg.outputs(last)
-    status = outs["status"].cpu().numpy()
-    out_np = outs["out"].cpu().numpy()
-    iters_np = outs["iters"].cpu().numpy()
+        if last == 0:                                               # slot 0 was just overwritten with the same results; nothing to restore
+            pass
     # the gathered copy of this rank's shard must be what the solver wrote
     g = pg.result(last)
-    gather_ok = bool(torch.equal(g["out"][rank if dist is not None else 0], outs["out"]) and
-                     torch.equal(g["status"][rank if dist is not None else 0], outs["status"]))
+    gather_ok = None
+    if g is not None:
+        gather_ok = bool(torch.equal(g["out"][rank if dist is not None else 0], outs["out"]) and
+                         torch.equal(g["status"][rank if dist is not None else 0], outs["status"]) and
+                         (g["traj"] is None or torch.equal(g["traj"][rank if dist is not None else 0], outs["traj"])))
 
     if rank != 0:
-        for h in mpcs:
-            h.close()
+        pipe.close()
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -341,9 +493,10 @@ def main():
     dtype = "f32" if f32 else "f64"
     total_solves = B * world * args.steps
     value = total_solves / elapsed
-    mean_iters = stats.iter_sum / max(1, stats.batch)
+    mean_iters = summary["mean_iterations"]
     stages = params.N - 1
-    is_headline = (params.N == 10 and not args.weights_sweep and B == 65536 and not f32 and args.config == "config-fast.json" and want_traj)
+    is_headline = (params.N == 10 and not args.weights_sweep and B == 65536 and not f32 and args.config == "config-fast.json" and want_traj
+                   and args.population == "filtered")
     res = {
         "metric": "%sMPC solves/sec (batch) at N=%d dt=%g" % ("STUB (not a measurement) " if stub else "", params.N, params.dt),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -354,18 +507,23 @@ def main():
                                   "on" if want_traj else "off", ", per-instance weight sweep" if args.weights_sweep else "",
                                   ", MPC_PRECISION_F32" if f32 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
-                   "parallelism": "%d independent shard(s), one all_gather_into_tensor of the packed results per batch" % world,
-                   "collective_mode": pg.mode, "gather_checked": gather_ok, "batches_in_flight": nfl,
+                   "parallelism": "%d independent shard(s), one %s of the packed results per batch" % (world, pg.collective_name),
+                   "collective_mode": pg.mode, "gather_checked": gather_ok, "gather_bytes_sent_per_rank_per_batch": pg.bytes_sent_per_rank if pg.active else 0,
+                   "batches_in_flight": nfl,
                    "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
-                   "termination_polish": bool(params.polish), "pass_cuts": cuts,
-                   # the generator redraws instances the reference's own road model does not hold for (scenarios.py)
-                   "instance_filter": ("none (unfiltered draws)" if args.unfiltered else
-                                       "rejection sampling, %d draws for %d instances" % (batch["drawn"], B)),
+                   "termination_polish": bool(params.polish), "bound_relax_factor": params.bound_relax_factor, "pass_cuts": cuts,
+                   "deferred_tails": summary.get("tails", "off"), "tail_cut": pipe.tail,
+                   # the generator redraws instances the reference's own road model does not hold for (scenarios.py); the
+                   # `unfiltered` leg below is the same workload without that
+                   "population": args.population,
+                   "instance_filter": ("none (unfiltered draws)" if args.population == "unfiltered" else
+                                       "%s: %d draws for %d instances" % ("SURVEY 8d's rejection only" if args.population == "survey" else "rejection sampling",
+                                                                          batch["drawn"], B)),
                    "instance_filter_rejected": batch["rejected"]},
         "converged_fraction": float((status == 0).mean()),
-        "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(5)},
-        "mean_iterations": mean_iters, "max_iterations": int(stats.iter_max),
+        "status_counts": summary["status_counts"],
+        "mean_iterations": mean_iters, "max_iterations": summary["max_iterations"],
         # per-instance interior-point iterations of the last batch: the launch lasts as long as its slowest instance
         "iteration_quantiles": {q: int(np.quantile(iters_np, float(q))) for q in ("0.5", "0.9", "0.99", "0.999")},
         "iteration_histogram": {"<=8": int((iters_np <= 8).sum()), "9-12": int(((iters_np > 8) & (iters_np <= 12)).sum()),
@@ -397,6 +555,8 @@ def main():
             break
     flops_per_step = B * mean_iters * stages * KFLOP_PER_STAGE_ITER * 1e3
     step_s = elapsed / args.steps
+    valu_frac = flops_per_step / step_s / 1e12 / VALU_PEAK_TFLOPS[dtype]
+    traffic_frac = (traffic / step_s / 1e9 / HBM_PEAK_GBS) if traffic else None
     res["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                        "kernel": "mpc_solve_kernel<%s>" % ("float" if f32 else "double"),
@@ -405,15 +565,16 @@ def main():
                        "algorithmic_bytes_per_launch": algo_bytes,
                        # against the STEP time: with several batches in flight launches overlap, so a launch lasts longer than a step
                        "frac_vs_step": algo_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                       # what the kernel really streams (workspace) per step against the HBM peak -- the limit it sits on
+                       # WHAT BINDS (the mandated `frac` prices the algorithmic bytes, which are tiny against the arithmetic):
+                       # the workspace the kernel streams per sweep against the HBM peak, and the arithmetic against the vector peak
+                       "binds": "the workspace traffic the kernel creates (traffic_frac_of_hbm_peak) and vector-ALU issue (valu_frac); "
+                                "`frac` is the algorithmic-bytes number the bench contract asks for",
                        "traffic_gbs_vs_step": (traffic / step_s / 1e9) if traffic else None,
-                       "traffic_frac_of_hbm_peak": (traffic / step_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                       "note": "algorithmic bytes are tiny against the arithmetic (SURVEY.md 8d), so `frac` is small by construction; the "
-                               "kernel is balanced between instruction issue and the workspace it streams per sweep (`traffic`, DESIGN.md "
-                               "section 5); kernel_ms_avg is a launch that shares the device with the other batches in flight, "
-                               "kernel_ms_alone the same launch by itself",
+                       "traffic_frac_of_hbm_peak": traffic_frac,
+                       "note": "kernel_ms_avg is a launch that shares the device with the other batches in flight, kernel_ms_alone the same "
+                               "launch by itself; with deferred tails a launch ends at the cut and the stragglers run in the tail launches",
                        "valu_tflops": flops_per_step / step_s / 1e12,
-                       "valu_frac": flops_per_step / step_s / 1e12 / VALU_PEAK_TFLOPS[dtype], "valu_peak_tflops": VALU_PEAK_TFLOPS[dtype]}
+                       "valu_frac": valu_frac, "valu_peak_tflops": VALU_PEAK_TFLOPS[dtype]}
 
     if world == 1 and stub is None and not args.no_host_leg:
         # PCIe-inclusive: the same batch from pageable host arrays through mpc_solve_batch_host (fp64 entry point)
@@ -421,7 +582,7 @@ def main():
             hs = []
             for _ in range(3):
                 th = time.perf_counter()
-                rh = mpcs[0].solve_numpy(batch["state"], batch["coeffs"], batch["yaw_lo"], batch["yaw_hi"], weights=w_np, want_traj=want_traj)
+                rh = pipe.mpcs[0].solve_numpy(batch["state"], batch["coeffs"], batch["yaw_lo"], batch["yaw_hi"], weights=w_np, want_traj=want_traj)
                 hs.append(time.perf_counter() - th)
             host_ok = bool(np.array_equal(rh["out"], out_np) and np.array_equal(rh["status"], status))
             p1 = params.copy()
@@ -437,6 +598,11 @@ def main():
                                 "b1_latency_ms_median": 1e3 * float(np.median(lat[10:])), "b1_latency_ms_min": 1e3 * float(np.min(lat[10:])),
                                 "b1_kernel_ms": k1, "b1_iterations": int(r1["iters"][0]),
                                 "b1_note": "one MPC::solve() per telemetry message is what the reference does (mpc_main.cpp:167); includes the ctypes call"}
+    pipe.close()
+    if world == 1 and stub is None and not args.no_legs:
+        legs = extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all)
+        res["unfiltered"] = legs.pop("unfiltered")
+        res["other_configs"] = legs
     if world == 1 and stub is None and not args.no_cpu_baseline:
         one, allc, worst_steer, worst_acc, n_done = cpu_baseline_legs(args, batch, w_np, over, status, out_np, args.cpu_seconds)
         res["cpu_baseline"] = one
@@ -446,8 +612,6 @@ def main():
         res["parity_sample"] = n_done
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(res) + "\n").encode())
-    for h in mpcs:
-        h.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

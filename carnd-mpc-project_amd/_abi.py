@@ -15,7 +15,7 @@ MAX_N = 64
 ABI_VERSION = 3
 PRECISION_F64, PRECISION_F32 = 0, 1
 
-STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric"}
+STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric", 5: "pending"}
 ERR_NAMES = {0: "MPC_OK", -1: "MPC_ERR_INVALID", -2: "MPC_ERR_NO_DEVICE", -3: "MPC_ERR_HIP",
              -4: "MPC_ERR_UNSUPPORTED", -5: "MPC_ERR_IO"}
 
@@ -60,7 +60,7 @@ class MpcWireTelemetry(C.Structure):
 class MpcBatchStats(C.Structure):
     _fields_ = [("batch", C.c_int64), ("n_success", C.c_int64), ("n_maxiter", C.c_int64),
                 ("n_linesearch", C.c_int64), ("n_infeasible", C.c_int64), ("n_numeric", C.c_int64),
-                ("iter_sum", C.c_int64), ("iter_max", C.c_int32), ("reserved", C.c_int32),
+                ("iter_sum", C.c_int64), ("iter_max", C.c_int32), ("n_pending", C.c_int32),
                 ("kernel_ms", C.c_double)]
 
 
@@ -70,7 +70,8 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_synchronize", "mpc_get_stats", "mpc_debug_math", "mpc_run_batch_device",
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
-           "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device"]
+           "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device",
+           "mpc_last_batch_id", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info"]
 
 _lib = None
 
@@ -127,6 +128,13 @@ def library():
     L.mpc_rollout_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
     L.mpc_telemetry_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 4
     L.mpc_handle_device.argtypes = [C.c_void_p]
+    L.mpc_last_batch_id.argtypes = [C.c_void_p]
+    L.mpc_last_batch_id.restype = C.c_int64
+    L.mpc_tail_wait.argtypes = [C.c_void_p, C.c_int64]
+    L.mpc_tail_stream_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.mpc_tail_flush.argtypes = [C.c_void_p]
+    L.mpc_tail_pending.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.mpc_tail_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.mpc_wire_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(MpcWireTelemetry)]
     L.mpc_wire_format_steer.argtypes = [C.c_double, C.c_double, C.c_char_p, C.c_int64]
     L.mpc_wire_format_steer.restype = C.c_int64

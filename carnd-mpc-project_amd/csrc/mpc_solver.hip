@@ -56,6 +56,11 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
 constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
 constexpr int kCounterInts = 16;    /* two counters per phase */
 constexpr int kParkRows = 36;       /* Solver::PARK_N */
+constexpr int kTailMaxRing = 64;    /* deferred tails: batches whose stragglers may be outstanding at once */
+constexpr int kTailPerLaunch = 16;  /* queue slots one tail launch serves (they travel as kernel arguments) */
+constexpr int kTailMaxStreams = 4;  /* tail launches that may run side by side */
+constexpr int kTailInRows = 6 + MPC_NCOEF + 2 + MPC_NW;   /* the inputs of a deferred instance travel with it: 25 rows */
+constexpr int kTailRows = kParkRows + kTailInRows;
 
 /*
  * One instance per lane.  Inputs/outputs are [quantity][instance] so that a wave's access to one
@@ -113,6 +118,14 @@ struct MpcPhase {
   /* Tile pool (MpcTilePool, optional): instead of tile number blockIdx of the handle's own workspace a wave takes a free
    * tile from the pool of ITS XCD and gives it back when it leaves, so that the addresses the device cycles through are
    * the tiles of the resident waves and not those of every batch in flight. */
+  /* Deferred tails (MpcParams.tail_cut): an instance still running after tail_cut passes is handed to the handle's tail
+   * queue -- solver scalars, its inputs and its current iterate are COPIED out, so the lane and the workspace are free at
+   * once -- and reported as MPC_STATUS_PENDING; mpc_tail_kernel finishes it from another stream.  A full queue (t_cap) makes
+   * the instance finish here after all. */
+  int32_t tail_cut, t_cap;
+  int32_t *t_count, *t_inst;       /* entries of this batch's queue slot: how many, which instance */
+  double *t_park;                  /* [kTailRows][t_cap]: Solver::park scalars, then state 6, coeffs 5, yaw_lo, yaw_hi, weights 12 */
+  void *t_iter;                    /* [t_cap / 64][N-1][IT_SZ][64] reals: the current iterate, tile of 64 entries */
   unsigned long long *pool_bits;   /* [8][pool_words]: bit set = tile free; nullptr = no pool */
   void *pool_base;                 /* [8][pool_tiles] tiles */
   int32_t pool_tiles, pool_words;  /* per XCD */
@@ -173,6 +186,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   SV S(P, ws);
   int64_t i = 0;
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
+  bool queue_full = false;                       /* deferred tails: the batch's queue slot has no room left */
   int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0;
   const int64_t n_work = T.resume ? (int64_t)*T.n_in : B;
   for (;;) {
@@ -243,6 +257,28 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           S.start_point();
           S.begin(false);
         } else { fin = true; fin_status = r; have = false; }
+      } else if (T.tail_cut > 0 && passes >= T.tail_cut && S.phase == SV::PH_DIR && !queue_full) {
+        const int pos = atomicAdd(T.t_count, 1);
+        if (pos >= T.t_cap) queue_full = true;      /* it finishes here, and so does whatever else this lane takes */
+        else {
+          T.t_inst[pos] = (int32_t)i;
+          double *pk = T.t_park + pos;
+          const int64_t lp = T.t_cap;
+          S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
+          pk += kParkRows * lp;
+          for (int q = 0; q < 6; q++) pk[q * lp] = (double)state[q * ld + i];
+          for (int q = 0; q < MPC_NCOEF; q++) pk[(6 + q) * lp] = (double)coeffs[q * ld + i];
+          pk[11 * lp] = (double)yaw_lo[i]; pk[12 * lp] = (double)yaw_hi[i];
+          for (int q = 0; q < MPC_NW; q++) pk[(13 + q) * lp] = weights ? (double)weights[q * ld + i] : P.weights[q];
+          ws.stage_drain();                          /* the trial sweep's stores of this wave have landed */
+          const int I = S.cur ? FL::IT1 : FL::IT0, M = P.N - 1;
+          R *dst = (R *)T.t_iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
+          for (int k = 0; k < M; ++k)
+            for (int f = 0; f < FL::IT_SZ; f++) dst[(k * FL::IT_SZ + f) * 64] = ws.it(k, I, f);
+          status[i] = MPC_STATUS_PENDING;
+          if (iters) iters[i] = S.iters + it_total;
+          have = false;                              /* the lane takes its next instance at the next hand-over */
+        }
       } else if (T.pass_cut > 0 && passes >= T.pass_cut && S.phase == SV::PH_DIR) {
         /* still running: park it for the next phase */
         const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
@@ -262,6 +298,118 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     if (threadIdx.x == 0) atomicOr(pool_mine + pool_word, 1ull << pool_bit);
   }
 #endif
+}
+
+/* Deferred tails: finishes the instances that the launches of several batches handed over (MpcPhase.tail_cut).  Same
+ * solver, same arithmetic -- the results are bitwise those of an undisturbed launch -- on the handle's tail stream, a few
+ * dense waves beside the launches of later batches.  The queue slots of up to kTailPerLaunch batches are served by one launch;
+ * a lane takes entries in turn (global counter) until none is left. */
+struct MpcTailSlot {
+  void *out, *traj;                /* the batch's output arrays (as given to mpc_solve_batch_device), leading dimension ldo */
+  int32_t *status, *iters;
+  int64_t ldo;
+  const int32_t *count, *inst;
+  const double *park;
+  const void *iter;
+};
+struct MpcTailArgs {
+  int32_t n_slots, cap;
+  int32_t *take;
+  int32_t refill_min, refill_wait;
+  MpcTailSlot slot[kTailPerLaunch];
+};
+
+template <bool STAGING, class R, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P, const MpcTailArgs A, R *__restrict__ wsbase,
+                                                               const int64_t tile_reals) {
+  extern __shared__ double smem[];
+  using WS = mpc::TiledWorkspace<STAGING, R>;
+  using SV = mpc::Solver<WS, R>;
+  using FL = mpc::Fields<R>;
+  WS ws;
+  ws.tile = (typename WS::greal *)(wsbase + (int64_t)blockIdx.x * tile_reals);
+  ws.lane = threadIdx.x;
+  ws.lbuf = (typename WS::lreal *)smem;
+  SV S(P, ws);
+  int64_t total = 0;
+  for (int j = 0; j < A.n_slots; j++) { const int c = *A.slot[j].count; total += c < A.cap ? c : A.cap; }
+  int64_t i = 0;
+  int sj = 0;                                      /* the queue slot (= batch) of the instance this lane holds */
+  R ylo_user = 0, yhi_user = 0;
+  bool have = false, more = true, fin = false;
+  int attempt = 0, it_total = 0, fin_status = 0, waited = 0;
+  const int M = P.N - 1;
+  for (;;) {
+    const int n_wait = MPC_WAVE_COUNT(fin || (!have && more));
+    if (n_wait > 0) {
+      if (!MPC_WAVE_ANY(have) || n_wait >= A.refill_min || waited >= A.refill_wait) {
+        waited = 0;
+        if (fin) {
+          for (int j = 0; j < A.n_slots; j++)        /* uniform j: the slot's pointers come through the scalar unit */
+            if (j == sj) {
+              const MpcTailSlot &D = A.slot[j];
+              R *o = (R *)D.out + i;
+              R *t = D.traj ? (R *)D.traj + i : nullptr;
+              const int64_t l = D.ldo;
+              S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, t != nullptr, ylo_user, yhi_user);
+              D.status[i] = fin_status;
+              if (D.iters) D.iters[i] = S.iters + it_total;
+            }
+          fin = false;
+        }
+        if (!have && more) {
+          int64_t g = (int64_t)atomicAdd(A.take, 1);
+          more = g < total;
+          if (more) {
+            sj = 0;
+            for (int j = 0; j < A.n_slots; j++) {
+              const int c0 = *A.slot[j].count, c = c0 < A.cap ? c0 : A.cap;
+              if (g >= c && j == sj) { g -= c; sj = j + 1; }
+            }
+            for (int j = 0; j < A.n_slots; j++)
+              if (j == sj) {
+                const MpcTailSlot &D = A.slot[j];
+                const int pos = (int)g;
+                i = D.inst[pos];
+                const double *pk = D.park + pos;
+                const int64_t lp = A.cap;
+                const double *pin = pk + kParkRows * lp;
+                R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+                for (int q = 0; q < 6; q++) st[q] = (R)pin[q * lp];
+#pragma unroll
+                for (int q = 0; q < MPC_NCOEF; q++) cf[q] = (R)pin[(6 + q) * lp];
+#pragma unroll
+                for (int q = 0; q < MPC_NW; q++) w[q] = (R)pin[(13 + q) * lp];
+                ylo_user = (R)pin[11 * lp]; yhi_user = (R)pin[12 * lp];
+                (void)S.setup(st, cf, ylo_user, yhi_user, w, false);
+                S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
+                const R *src = (const R *)D.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
+                const int I = S.cur ? FL::IT1 : FL::IT0;
+                for (int k = 0; k < M; ++k) {
+                  R rec[FL::IT_SZ];
+#pragma unroll
+                  for (int f = 0; f < FL::IT_SZ; f++) rec[f] = src[(k * FL::IT_SZ + f) * 64];
+                  ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+                }
+                have = true;
+              }
+          }
+        }
+      } else ++waited;
+    }
+    if (!MPC_WAVE_ANY(have || more || fin)) break;
+    if (have) {
+      const int r = S.step();
+      if (r != SV::MPC_RUNNING) {
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+          attempt = 1; it_total += S.iters;
+          S.start_point();
+          S.begin(false);
+        } else { fin = true; fin_status = r; have = false; }
+      }
+    }
+  }
 }
 
 /* Small launches: the N-step variables of every instance resident in LDS (mpc::LdsWorkspace), one instance per lane,
@@ -373,11 +521,12 @@ __global__ __launch_bounds__(256) void mpc_stats_kernel(int64_t B, const int32_t
   if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) { isum = 0; imax = 0; }
   __syncthreads();
-  unsigned int my[5] = {0, 0, 0, 0, 0};
+  unsigned int my[5] = {0, 0, 0, 0, 0}, pend = 0;
   unsigned long long ms = 0;
   int mm = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t st = status[i];
+    if (st == MPC_STATUS_PENDING) { ++pend; continue; }   /* deferred: counted, its iterations are not final */
     const int c = (st >= 0 && st < 4) ? st : 4;
 #pragma unroll
     for (int q = 0; q < 5; q++) my[q] += (c == q);
@@ -389,6 +538,7 @@ __global__ __launch_bounds__(256) void mpc_stats_kernel(int64_t B, const int32_t
   for (int q = 0; q < 5; q++) if (my[q]) atomicAdd(&cnt[q], my[q]);
   if (ms) atomicAdd(&isum, ms);
   if (mm) atomicMax(&imax, mm);
+  if (pend) atomicAdd(&acc[7], (unsigned long long)pend);
   __syncthreads();
   if (threadIdx.x < 5 && cnt[threadIdx.x]) atomicAdd(&acc[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
   if (threadIdx.x == 5 && isum) atomicAdd(&acc[5], isum);
@@ -486,6 +636,28 @@ struct MpcHandle {
   double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
+  /* deferred tails (MpcParams.tail_cut > 0; allocated on first use) */
+  struct TailSlot {
+    int64_t batch_id = 0;        /* the batch whose stragglers sit in this queue slot (0: never used) */
+    int64_t launch = -1;         /* the tail launch that serves it (-1: none yet) */
+    void *out = nullptr, *traj = nullptr; int32_t *status = nullptr, *iters = nullptr; int64_t ldo = 0;
+    hipEvent_t bulk = nullptr;   /* recorded behind the batch's own launch */
+  };
+  bool tail_ready = false;
+  int tail_ring = 0, tail_waves = 256, tail_priority = 0;
+  int64_t tail_cap = 0, tail_min_batch = 4096;
+  int n_tail_streams = 2;
+  hipStream_t tail_stream[kTailMaxStreams] = {};
+  int64_t stream_launch[kTailMaxStreams] = {-1, -1, -1, -1};   /* the most recent tail launch on each of them */
+  int32_t *d_tcount = nullptr, *d_tinst = nullptr, *d_ttake = nullptr;
+  double *d_tpark = nullptr;
+  void *d_titer = nullptr, *tail_ws = nullptr;
+  size_t titer_slot_bytes = 0;
+  TailSlot tslot[kTailMaxRing];
+  hipEvent_t tail_ev[kTailMaxRing] = {};
+  int64_t batch_seq = 0;         /* id of the most recent batch (every solve call counts) */
+  int64_t n_deferred = 0;        /* deferred batches so far: batch k of them uses queue slot k % tail_ring */
+  int64_t n_tail_launch = 0;
   double *d_tel = nullptr;       /* mpc_telemetry_batch_host: device staging, grown on demand */
   size_t tel_bytes = 0;
   /* last call */
@@ -524,6 +696,7 @@ static int validate_params(const MpcParams *p) {
   if (p->precision != MPC_PRECISION_F64 && p->precision != MPC_PRECISION_F32) { g_last_error = "unknown precision"; return MPC_ERR_INVALID; }
   if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
+  if (p->tail_cut < 0 || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
   return MPC_OK;
 }
 
@@ -651,6 +824,9 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   int rc = validate_params(p);
   if (rc != MPC_OK) return rc;
   if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
+  if (h->tail_ready && (p->tail_ring != h->params.tail_ring || p->tail_capacity != h->params.tail_capacity)) {
+    g_last_error = "tail_ring and tail_capacity cannot change once the tail queue exists"; return MPC_ERR_INVALID;
+  }
   h->params = *p;
   set_cuts(h, p);
   return MPC_OK;
@@ -676,6 +852,14 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_park) (void)hipFree(h->d_park);
   if (h->d_list) (void)hipFree(h->d_list);
   if (h->d_tel) (void)hipFree(h->d_tel);
+  for (int q = 0; q < kTailMaxStreams; q++) if (h->tail_stream[q]) (void)hipStreamSynchronize(h->tail_stream[q]);
+  for (void *q : {(void *)h->d_tcount, (void *)h->d_tinst, (void *)h->d_ttake, (void *)h->d_tpark, h->d_titer, h->tail_ws})
+    if (q) (void)hipFree(q);
+  for (int q = 0; q < kTailMaxRing; q++) {
+    if (h->tslot[q].bulk) (void)hipEventDestroy(h->tslot[q].bulk);
+    if (h->tail_ev[q]) (void)hipEventDestroy(h->tail_ev[q]);
+  }
+  for (int q = 0; q < kTailMaxStreams; q++) if (h->tail_stream[q]) (void)hipStreamDestroy(h->tail_stream[q]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -714,11 +898,196 @@ static int launch_lds(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R 
   }
 }
 
+/* ---- deferred tails: queue storage, the tail launch, waiting for a batch ---- */
+static int tail_prepare(MpcHandle *h, size_t real_bytes) {
+  if (h->tail_ready) return MPC_OK;
+  const MpcParams &P = h->params;
+  const bool f32 = P.precision == MPC_PRECISION_F32;
+  h->tail_ring = P.tail_ring < 2 ? 2 : (P.tail_ring > kTailMaxRing ? kTailMaxRing : P.tail_ring);
+  int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 8;
+  if (cap < 256) cap = 256;
+  if (cap > h->io_stride) cap = h->io_stride;
+  h->tail_cap = (cap + 63) / 64 * 64;
+  if (const char *e = getenv("MPC_TAIL_WAVES")) { h->tail_waves = atoi(e); if (h->tail_waves < 1) h->tail_waves = 1; }
+  if (const char *e = getenv("MPC_TAIL_MIN_BATCH")) { h->tail_min_batch = atoll(e); if (h->tail_min_batch < 1) h->tail_min_batch = 1; }
+  const int64_t max_tail_waves = (h->tail_cap / 64) * h->tail_ring;
+  if (h->tail_waves > max_tail_waves) h->tail_waves = (int)max_tail_waves;
+  /* The tail stream's priority.  Stragglers are few waves with long serial chains: they should start as soon as a
+   * SIMD is free, so the default is the HIGH priority (MPC_TAIL_PRIORITY=low|normal|high to measure the others). */
+  int lo = 0, hi = 0;
+  MPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      /* lo = least, hi = greatest priority (numerically smaller) */
+  int prio = hi;
+  if (const char *e = getenv("MPC_TAIL_PRIORITY")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "normal") ? 0 : hi);
+  h->tail_priority = prio;
+  /* Tail launches side by side: a launch lasts as long as its slowest straggler (up to 2 x max_iter iterations with the
+   * restart: tens of milliseconds), and a batch is final only when the launch that serves it is; with one launch at a time a
+   * batch waits for the running launch AND its own, with S of them for 1/S of the running one. */
+  if (const char *e = getenv("MPC_TAIL_STREAMS")) h->n_tail_streams = atoi(e);
+  if (h->n_tail_streams < 1) h->n_tail_streams = 1;
+  if (h->n_tail_streams > kTailMaxStreams) h->n_tail_streams = kTailMaxStreams;
+  for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream[q], hipStreamNonBlocking, prio));
+  const int64_t K = h->tail_ring, cp = h->tail_cap;
+  const int M = P.N - 1;
+  const size_t it_sz = f32 ? (size_t)mpc::Fields<float>::IT_SZ : (size_t)mpc::Fields<double>::IT_SZ;
+  h->titer_slot_bytes = (size_t)(cp / 64) * M * it_sz * 64 * real_bytes;
+  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->d_ttake, sizeof(int32_t) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tinst, sizeof(int32_t) * K * cp));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tpark, sizeof(double) * K * kTailRows * cp));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->d_titer, h->titer_slot_bytes * K));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)h->ws_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
+  for (int q = 0; q < kTailMaxRing; q++) {
+    MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tslot[q].bulk, hipEventDisableTiming));
+    MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tail_ev[q], hipEventDisableTiming));
+  }
+  h->tail_ready = true;
+  return MPC_OK;
+}
+
+/* Tail launches for every deferred batch that none serves yet (kTailPerLaunch batches per launch), on tail stream `si`
+ * (-1: the first idle one, else the one whose launch is the oldest) */
+static int tail_flush(MpcHandle *h, int si = -1) {
+  if (!h->tail_ready) return MPC_OK;
+  int order[kTailMaxRing];
+  int n = 0;
+  for (int q = 0; q < h->tail_ring; q++)
+    if (h->tslot[q].batch_id != 0 && h->tslot[q].launch < 0) order[n++] = q;
+  if (n == 0) return MPC_OK;
+  for (int a = 1; a < n; a++)           /* oldest batch first */
+    for (int b = a; b > 0 && h->tslot[order[b]].batch_id < h->tslot[order[b - 1]].batch_id; b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  if (si < 0) {
+    si = 0;
+    for (int q = 0; q < h->n_tail_streams; q++) if (h->stream_launch[q] < h->stream_launch[si]) si = q;
+  }
+  const int64_t cp = h->tail_cap;
+  const bool f32 = h->params.precision == MPC_PRECISION_F32;
+  const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
+  for (int first = 0; first < n; first += kTailPerLaunch) {
+    const int m = n - first < kTailPerLaunch ? n - first : kTailPerLaunch;
+    MpcTailArgs A;
+    memset(&A, 0, sizeof(A));
+    const int64_t L = h->n_tail_launch;
+    hipStream_t ts = h->tail_stream[si];
+    for (int a = 0; a < m; a++) {
+      const int q = order[first + a];
+      MpcHandle::TailSlot &S = h->tslot[q];
+      MPC_HIP_CHECK(hipStreamWaitEvent(ts, S.bulk, 0));
+      MpcTailSlot &D = A.slot[a];
+      D.out = S.out; D.traj = S.traj; D.status = S.status; D.iters = S.iters; D.ldo = S.ldo;
+      D.count = h->d_tcount + q; D.inst = h->d_tinst + (int64_t)q * cp; D.park = h->d_tpark + (int64_t)q * kTailRows * cp;
+      D.iter = (const char *)h->d_titer + (size_t)q * h->titer_slot_bytes;
+      S.launch = L;
+    }
+    A.n_slots = m; A.cap = (int32_t)cp; A.take = h->d_ttake + (L % kTailMaxRing);
+    A.refill_min = 1; A.refill_wait = 0;       /* a finished lane is served at once: the waves of this launch are few and long-lived */
+    MPC_HIP_CHECK(hipMemsetAsync(A.take, 0, sizeof(int32_t), ts));
+    int64_t waves = (int64_t)m * (cp / 64);
+    if (waves > h->tail_waves) waves = h->tail_waves;
+    void *wsp = (char *)h->tail_ws + (size_t)si * (size_t)h->ws_stride * (size_t)h->tail_waves * real_bytes;
+    if (f32 && h->occ2)
+      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 2>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, h->ws_stride);
+    else if (f32)
+      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, h->ws_stride);
+    else
+      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, h->ws_stride);
+    MPC_HIP_CHECK(hipGetLastError());
+    MPC_HIP_CHECK(hipEventRecord(h->tail_ev[L % kTailMaxRing], ts));
+    h->stream_launch[si] = L;
+    ++h->n_tail_launch;
+  }
+  return MPC_OK;
+}
+
+/* self-clocked: a tail stream whose previous launch has finished takes everything that came in meanwhile */
+static int tail_clock(MpcHandle *h) {
+  for (int q = 0; q < h->n_tail_streams; q++) {
+    bool idle = h->stream_launch[q] < 0;
+    if (!idle) {
+      const hipError_t e = hipEventQuery(h->tail_ev[h->stream_launch[q] % kTailMaxRing]);
+      if (e == hipSuccess) idle = true;
+      else if (e != hipErrorNotReady) { g_last_error = std::string("hipEventQuery: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
+      else (void)hipGetLastError();
+    }
+    if (idle) return tail_flush(h, q);
+  }
+  return MPC_OK;
+}
+
+/* the queue slot that holds batch `id`, or nullptr: the batch was not deferred, or it is so old that its slot has been
+ * taken again -- which only happens after its tail launch has been waited for */
+static MpcHandle::TailSlot *tail_slot_of(MpcHandle *h, int64_t id) {
+  for (int q = 0; q < h->tail_ring; q++)
+    if (h->tslot[q].batch_id == id) return &h->tslot[q];
+  return nullptr;
+}
+
+extern "C" int64_t mpc_last_batch_id(const MpcHandle *h) { return h ? h->batch_seq : 0; }
+
+extern "C" int mpc_tail_flush(MpcHandle *h) {
+  if (!h) return MPC_ERR_INVALID;
+  MPC_ON_DEVICE(h);
+  return tail_flush(h);
+}
+
+extern "C" int mpc_tail_wait(MpcHandle *h, int64_t batch_id) {
+  if (!h) return MPC_ERR_INVALID;
+  if (!h->tail_ready) return MPC_OK;
+  MPC_ON_DEVICE(h);
+  if (batch_id <= 0) {                         /* everything handed over so far */
+    const int rf = tail_flush(h);
+    if (rf != MPC_OK) return rf;
+    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
+    return MPC_OK;
+  }
+  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
+  if (!S) return MPC_OK;
+  if (S->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+  if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;     /* its event has been recycled: that launch is long done */
+  MPC_HIP_CHECK(hipEventSynchronize(h->tail_ev[S->launch % kTailMaxRing]));
+  return MPC_OK;
+}
+
+extern "C" int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream) {
+  if (!h) return MPC_ERR_INVALID;
+  if (!h->tail_ready) return MPC_OK;
+  MPC_ON_DEVICE(h);
+  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
+  if (!S) return MPC_OK;
+  if (S->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+  if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;
+  MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->tail_ev[S->launch % kTailMaxRing], 0));
+  return MPC_OK;
+}
+
+/* counters of the handle's tail machinery: out[0] batches deferred so far, [1] tail launches so far, [2] ring, [3] queue
+ * capacity per batch, [4] waves per tail launch (upper bound), [5] 1 if the tail streams have high priority, [6] tail streams */
+extern "C" int mpc_tail_info(const MpcHandle *h, int64_t *out6) {   /* (seven values) */
+  if (!h || !out6) return MPC_ERR_INVALID;
+  out6[0] = h->n_deferred; out6[1] = h->n_tail_launch; out6[2] = h->tail_ring; out6[3] = h->tail_cap; out6[4] = h->tail_waves;
+  out6[5] = h->tail_priority < 0 ? 1 : 0; out6[6] = h->n_tail_streams;
+  return MPC_OK;
+}
+
+extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
+  if (!h || !n) return MPC_ERR_INVALID;
+  *n = 0;
+  if (!h->tail_ready) return MPC_OK;
+  MPC_ON_DEVICE(h);
+  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
+  if (!S) return MPC_OK;
+  MPC_HIP_CHECK(hipEventSynchronize(S->bulk));
+  int32_t c = 0;
+  MPC_HIP_CHECK(hipMemcpy(&c, h->d_tcount + (S - h->tslot), sizeof(c), hipMemcpyDeviceToHost));
+  *n = c < h->tail_cap ? c : h->tail_cap;
+  return MPC_OK;
+}
+
 /* the launch; ld = leading dimension of the inputs, ldo = of out/traj */
 template <class R>
 static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs,
                         const R *yaw_lo, const R *yaw_hi, const R *weights, R *out, R *traj,
-                        int32_t *status, int32_t *iters, void *stream_, bool with_stats = true) {
+                        int32_t *status, int32_t *iters, void *stream_, bool with_stats = true, bool may_defer = false) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
   if ((h->params.precision == MPC_PRECISION_F32) != (sizeof(R) == 4)) {
     g_last_error = "this handle was created with the other precision: fp64 handles take the double entry points, "
@@ -728,6 +1097,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   if (B < 0 || ld < B || ldo < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
   h->last_B = B; h->timed = false; h->have_stats = false;
+  ++h->batch_seq;
   if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   MPC_ON_DEVICE(h);   /* workspace, lazy allocations and a NULL stream all belong to the handle's device */
@@ -736,7 +1106,23 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  const int n_cuts = (h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
+  const bool defer = may_defer && h->params.tail_cut > 0 && B >= h->tail_min_batch && !(h->lds_lanes > 0 && B <= h->lds_max_batch);
+  const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
+  MpcHandle::TailSlot *ts = nullptr;
+  int slot_index = 0;
+  if (defer) {
+    const int rc = tail_prepare(h, sizeof(R));
+    if (rc != MPC_OK) return rc;
+    slot_index = (int)(h->n_deferred % h->tail_ring);
+    ts = &h->tslot[slot_index];
+    if (ts->batch_id != 0) {
+      /* the queue slot is taken again: whatever it held must have been served (if the tails are slower than ring x
+       * batches, this is where the caller's stream waits for them) */
+      if (ts->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+      MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->tail_ev[ts->launch % kTailMaxRing], 0));
+    }
+    MPC_HIP_CHECK(hipMemsetAsync(h->d_tcount + slot_index, 0, sizeof(int32_t), (hipStream_t)stream_));
+  }
   if (n_cuts > 0 && !h->ws2) {
     const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(R);
     MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
@@ -786,6 +1172,11 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
     T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    T.tail_cut = defer ? h->params.tail_cut : 0; T.t_cap = (int32_t)h->tail_cap;
+    T.t_count = defer ? h->d_tcount + slot_index : nullptr;
+    T.t_inst = defer ? h->d_tinst + (int64_t)slot_index * h->tail_cap : nullptr;
+    T.t_park = defer ? h->d_tpark + (int64_t)slot_index * kTailRows * h->tail_cap : nullptr;
+    T.t_iter = defer ? (void *)((char *)h->d_titer + (size_t)slot_index * h->titer_slot_bytes) : nullptr;
     const bool pooled = h->pool && n_cuts == 0;      /* a parked iterate stays in its column: phases keep their own tiles */
     T.pool_bits = pooled ? h->pool->bits : nullptr; T.pool_base = pooled ? h->pool->base : nullptr;
     T.pool_tiles = pooled ? h->pool->tiles : 0; T.pool_words = pooled ? h->pool->words : 0;
@@ -795,6 +1186,15 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
+  if (defer) {
+    ts->batch_id = h->batch_seq; ts->launch = -1;
+    ts->out = out; ts->traj = traj; ts->status = status; ts->iters = iters; ts->ldo = ldo;
+    MPC_HIP_CHECK(hipEventRecord(ts->bulk, s));
+    ++h->n_deferred;
+    /* self-clocked: a tail launch goes out whenever a tail stream has finished its previous one, and serves every batch that
+     * came in meanwhile -- so however long the stragglers take, no launch queues behind another */
+    { const int rf = tail_clock(h); if (rf != MPC_OK) return rf; }
+  }
   if (with_stats) return record_stats(h, B, status, it_out, s);
   return MPC_OK;
 }
@@ -803,7 +1203,7 @@ extern "C" int mpc_solve_batch_device(MpcHandle *h, int64_t B, int64_t ld, const
                                       const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                                       const double *weights, double *out, double *traj, int32_t *status,
                                       int32_t *iters, void *stream_) {
-  return launch_solve<double>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
+  return launch_solve<double>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_, true, true);
 }
 
 /* MPC_PRECISION_F32: the same solve with fp32 inputs, outputs and workspace (handle created with precision F32) */
@@ -811,7 +1211,7 @@ extern "C" int mpc_solve_batch_device_f32(MpcHandle *h, int64_t B, int64_t ld, c
                                           const float *coeffs, const float *yaw_lo, const float *yaw_hi,
                                           const float *weights, float *out, float *traj, int32_t *status,
                                           int32_t *iters, void *stream_) {
-  return launch_solve<float>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_);
+  return launch_solve<float>(h, B, ld, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, stream_, true, true);
 }
 
 /* run() for a batch; `tel` selects the telemetry rows as input (with latency compensation) and `cmd` the reply */
@@ -934,6 +1334,11 @@ extern "C" int mpc_synchronize(MpcHandle *h) {
   if (!h) return MPC_ERR_INVALID;
   MPC_ON_DEVICE(h);
   MPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (h->tail_ready) {
+    const int rf = tail_flush(h);
+    if (rf != MPC_OK) return rf;
+    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
+  }
   return MPC_OK;
 }
 
@@ -993,7 +1398,7 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
   MPC_HIP_CHECK(hipMemcpy(acc, h->d_stats, sizeof(acc), hipMemcpyDeviceToHost));
   st->n_success = (int64_t)acc[MPC_STATUS_SUCCESS]; st->n_maxiter = (int64_t)acc[MPC_STATUS_MAXITER];
   st->n_linesearch = (int64_t)acc[MPC_STATUS_LINESEARCH]; st->n_infeasible = (int64_t)acc[MPC_STATUS_INFEASIBLE];
-  st->n_numeric = (int64_t)acc[4]; st->iter_sum = (int64_t)acc[5]; st->iter_max = (int32_t)acc[6];
+  st->n_numeric = (int64_t)acc[4]; st->iter_sum = (int64_t)acc[5]; st->iter_max = (int32_t)acc[6]; st->n_pending = (int32_t)acc[7];
   if (h->timed) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;

@@ -136,7 +136,10 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     inside the 6-point window), or a final fit error above Config::maxFitError (RoadGeometry.cpp:34).
     The returned dict carries the counts ("drawn", "rejected": per criterion) so that callers can report them;
     filtered=False keeps every draw with a finite fit (the unfiltered population: the solver then reports the
-    infeasible / non-converged ones through its per-instance status)."""
+    infeasible / non-converged ones through its per-instance status); filtered="survey" applies exactly the rejection
+    SURVEY.md section 8d names for this generator -- compensated speed above Config::maxSpeed (the reference's NLP has no
+    feasible point then) -- and nothing else: waypoint windows that double back and fits above Config::maxFitError stay
+    in, as they would reach the reference's solver (RoadGeometry.cpp:26-34 stops raising the order and solves anyway)."""
     wp = np.asarray(waypoints, dtype=np.float64)
     nwp = len(wp)
     g = _rng(seed, stream)
@@ -179,7 +182,7 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
         c_fin = np.isfinite(pre["coeffs"]).all(axis=0)
         c_mono = (np.diff(pre["ptsx_vehicle"], axis=1) > 0).all(axis=1)
         c_fit = pre["fiterr"] <= params.max_fit_error
-        ok = (c_speed & c_yaw & c_fin & c_mono & c_fit) if filtered else c_fin
+        ok = (c_speed & c_fin) if filtered == "survey" else ((c_speed & c_yaw & c_fin & c_mono & c_fit) if filtered else c_fin)
         take = np.flatnonzero(ok)[:need]
         used = (take[-1] + 1) if len(take) == need and len(take) else n      # draws looked at in this round
         drawn += int(used)
@@ -200,7 +203,8 @@ def lake_track_batch(B, params, waypoints, seed=DEFAULT_SEED, stream=3, latency_
     for k in two_d:
         out[k] = np.ascontiguousarray(out[k])
     out["drawn"] = drawn
-    out["rejected"] = rej if filtered else {"nonfinite_fit": rej["nonfinite_fit"]}
+    out["rejected"] = ({"speed_above_max": rej["speed_above_max"], "nonfinite_fit": rej["nonfinite_fit"]} if filtered == "survey" else
+                       rej if filtered else {"nonfinite_fit": rej["nonfinite_fit"]})
     return out
 
 

@@ -174,6 +174,31 @@ class BatchedMPC:
                                              p(out), p(traj), p(status), p(iters)), "mpc_solve_batch_host")
         return {"out": out, "status": status, "iters": iters, "traj": traj}
 
+    # -- deferred tails (MpcParams.tail_cut > 0, include/mpc_amd.h) -------------
+    def last_batch_id(self):
+        return int(library().mpc_last_batch_id(self._h))
+
+    def tail_wait(self, batch_id=0):
+        """Block until batch `batch_id` is final (0: every batch issued so far)."""
+        check(library().mpc_tail_wait(self._h, int(batch_id)), "mpc_tail_wait")
+
+    def tail_stream_wait(self, batch_id, stream):
+        check(library().mpc_tail_stream_wait(self._h, int(batch_id), C.c_void_p(stream.cuda_stream)), "mpc_tail_stream_wait")
+
+    def tail_flush(self):
+        check(library().mpc_tail_flush(self._h), "mpc_tail_flush")
+
+    def tail_pending(self, batch_id):
+        n = C.c_int64(0)
+        check(library().mpc_tail_pending(self._h, int(batch_id), C.byref(n)), "mpc_tail_pending")
+        return int(n.value)
+
+    def tail_info(self):
+        a = (C.c_int64 * 7)()
+        check(library().mpc_tail_info(self._h, a), "mpc_tail_info")
+        return {"batches_deferred": int(a[0]), "tail_launches": int(a[1]), "ring": int(a[2]), "capacity_per_batch": int(a[3]),
+                "waves_per_tail_launch": int(a[4]), "tail_stream_high_priority": bool(a[5]), "tail_streams": int(a[6])}
+
     def synchronize(self):
         check(library().mpc_synchronize(self._h), "mpc_synchronize")
 

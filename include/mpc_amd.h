@@ -54,7 +54,8 @@ enum {
   MPC_STATUS_MAXITER = 1,
   MPC_STATUS_LINESEARCH = 2,   /* step length fell below alpha_min (IPOPT: restoration) */
   MPC_STATUS_INFEASIBLE = 3,   /* initial state outside its own bounds (MPC.cpp:229-239 vs :269-281) */
-  MPC_STATUS_NUMERIC = 4       /* NaN/Inf met */
+  MPC_STATUS_NUMERIC = 4,      /* NaN/Inf met */
+  MPC_STATUS_PENDING = 5       /* deferred tails only: handed to the tail queue, final after mpc_tail_wait */
 };
 
 enum { MPC_BRANCH_FROZEN = 0, MPC_BRANCH_LIVE = 1 };
@@ -126,7 +127,8 @@ typedef struct MpcParams {
    * launch ends; the queue is drained by a separate launch on the handle's own tail stream while later batches run.
    * mpc_tail_wait / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
   int32_t tail_cut;                /* default 0 = off */
-  int32_t tail_ring;               /* batches whose tails may be outstanding at once, default 16 */
+  int32_t tail_ring;               /* batches whose tails may be outstanding at once (2..64), default 32: a batch is final
+                                    * only when its slowest straggler is, tens of milliseconds behind its launch */
   int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 8.  A batch with more keeps the rest in its launch */
   /* Mixed precision across phases.  MPC_PRECISION_F32 handles: f32_finish = 1 (default) runs the interior-point
    * iteration in fp32 until its barrier parameter has reached mixed_switch_mu and finishes every instance in fp64
@@ -147,7 +149,7 @@ typedef struct MpcBatchStats {
   int64_t n_success, n_maxiter, n_linesearch, n_infeasible, n_numeric;
   int64_t iter_sum;          /* sum of interior-point iterations over the batch */
   int32_t iter_max;
-  int32_t reserved;
+  int32_t n_pending;         /* deferred tails: instances of the batch handed to the tail queue (their iterations are not in iter_sum yet) */
   double kernel_ms;          /* hipEvent time of the solve kernel, on its own stream */
 } MpcBatchStats;
 
@@ -263,6 +265,29 @@ int64_t mpc_wire_format_manual(char *buf, int64_t cap);
  * prev_throttle[B] or NULL: throttle of each connection's previous reply; cmd [2][B]: steering_angle row, throttle row. */
 int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcWireTelemetry *tel, const double *prev_throttle,
                                   double extra_latency, double *cmd, int32_t *status);
+/* ---- deferred tails (MpcParams.tail_cut > 0) ----------------------------------------------------------------
+ * A launch lasts as long as its slowest instance; on heavy-tailed workloads one 200-iteration straggler prices 65 536
+ * solves.  With tail_cut = n the launch of mpc_solve_batch_device(_f32) hands every instance that is still running after
+ * n passes to the handle's tail queue and ends: when the call's work on `stream` is complete, every other instance has
+ * its final results and the handed-over ones carry status MPC_STATUS_PENDING (mpc_tail_pending counts them).  They are
+ * finished by separate launches on the handle's own tail stream -- one launch at a time, each serving whatever the batches
+ * since the previous one handed over -- which write the same arrays; results are bitwise those of an undisturbed launch.
+ * The caller keeps a batch's output arrays alive and does not read its pending entries until the batch is final:
+ *   mpc_last_batch_id     id of the batch the most recent solve call issued (ids count up from 1 per handle)
+ *   mpc_tail_wait         blocks the host until batch `id` is final (id <= 0: every batch issued so far)
+ *   mpc_tail_stream_wait  makes `stream` wait for that instead (e.g. the stream a gather of the results runs on)
+ *   mpc_tail_flush        starts a tail launch for everything handed over so far without waiting (optional: the solve
+ *                         calls do that themselves whenever the previous tail launch has finished)
+ * At most tail_ring batches may be outstanding; issuing one more makes the caller's stream wait for the oldest tail.
+ * The run(), telemetry, rollout and host entry points never defer. */
+int64_t mpc_last_batch_id(const MpcHandle *h);
+int mpc_tail_wait(MpcHandle *h, int64_t batch_id);
+int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream);
+int mpc_tail_flush(MpcHandle *h);
+int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n);   /* waits for the batch's own launch, then: how many it handed over */
+/* out7: batches deferred so far, tail launches so far, ring, queue capacity per batch, waves per tail launch, 1 if the
+ * tail streams have high priority, number of tail streams (launches that may run side by side) */
+int mpc_tail_info(const MpcHandle *h, int64_t *out7);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);

@@ -554,3 +554,54 @@ def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N,
     ref = oracle_solve_batch(cfg, b, idx)
     assert (ref["status"] == 0).all(), np.bincount(ref["status"])
     assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "N=%d" % N)
+
+
+@pytest.mark.parametrize("case", ["headline", "weights", "f32", "N25"])
+def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_dev, case):
+    """MpcParams.tail_cut: instances still running after `tail_cut` passes leave their launch (status PENDING at the bulk's
+    completion) and are finished by the handle's tail launches; after mpc_tail_wait every array is bitwise what the single
+    launch writes.  Also with the queue slots recycled many times (ring of 2), with a queue too small for the batch
+    (the rest finishes in its launch), and with several batches outstanding."""
+    import torch
+    over = dict(N=25, dt=0.05) if case == "N25" else {}
+    cfgname = "config-stable.json" if case == "N25" else "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname), **over)
+    f32 = case == "f32"
+    if f32:
+        params.precision = pkg.PRECISION_F32
+    B = 8192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=71)
+    w = pkg.scenarios.weight_sweep(B, params, seed=72, velocity_weights=(0.0, 1.0, 100.0)) if case in ("weights", "f32") else None
+    tdt = torch.float32 if f32 else torch.float64
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=tdt)
+    ins = [t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"])]
+    d_w = t(w) if w is not None else None
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        ref = mpc.solve_torch(*ins, weights=d_w, want_traj=True)
+        torch.cuda.synchronize()
+        ref = {k: v.cpu().numpy() for k, v in ref.items()}
+    for cut, ring, cap, n_batches in ((8, 2, 0, 7), (14, 4, 0, 3), (5, 3, 256, 3)):
+        p = params.copy(); p.tail_cut = cut; p.tail_ring = ring; p.tail_capacity = cap
+        with pkg.BatchedMPC(p, B, device=0) as mpc:
+            outs = [mpc.alloc_outputs(B, torch_dev, True) for _ in range(n_batches)]
+            ids, pend_seen = [], []
+            for k in range(n_batches):
+                mpc.solve_torch(*ins, weights=d_w, outputs=outs[k])
+                ids.append(mpc.last_batch_id())
+            assert ids == list(range(1, n_batches + 1))
+            for k in range(n_batches):
+                pend_seen.append(mpc.tail_pending(ids[k]))          # waits for the bulk of that batch only
+            mpc.tail_wait(0)
+            torch.cuda.synchronize()
+            for k in range(n_batches):
+                got = {kk: v.cpu().numpy() for kk, v in outs[k].items()}
+                assert (got["status"] != 5).all(), (case, cut, k)
+                for kk in ("status", "iters", "out", "traj"):
+                    assert np.array_equal(got[kk], ref[kk], equal_nan=True), (case, cut, ring, cap, k, kk)
+            # the cut bites: the last ring's worth of batches report how many instances they handed over
+            n_over = int((ref["iters"] + 2 > cut).sum())
+            live = pend_seen[-min(ring, n_batches):]
+            if cap == 0:
+                assert all(0 < x <= n_over for x in live), (case, cut, live, n_over)
+            else:
+                assert all(x == 256 for x in live), (case, live)    # the queue filled up; everything else finished in its launch

@@ -64,16 +64,18 @@ def test_two_rank_shard_solve_gather(host_twin, B):
     assert cut == (0, (B + 1) // 2)
 
 
-def _worker_packed(rank, world, port, b, q):
-    """PackedGather (the bench's zero-copy gather) on CPU tensors over gloo: two alternating buffer sets."""
+def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True):
+    """PackedGather (the bench's zero-copy gather) on CPU tensors over gloo: two alternating buffer sets; all-gather or
+    gather to rank 0, with or without the trajectories in the payload."""
     sys.path.insert(0, ROOT)
     import __graft_entry__ as G
     pkg = G.load_package()
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = 10
-    pg = pkg.sharding.PackedGather(b, N, True, torch.device("cpu"))
+    pg = pkg.sharding.PackedGather(b, N, True, torch.device("cpu"), root_only=root_only, gather_traj=gather_traj)
     ok = pg.active and pg.ws == world and not pg.overlap          # overlap needs RCCL
+    ok = ok and pg.bytes_sent_per_rank == 8 * b * (10 + (2 * N if gather_traj else 0))
     for step in range(3):
         slot = step & 1
         pg.wait(slot)
@@ -86,9 +88,18 @@ def _worker_packed(rank, world, port, b, q):
         pg.start(slot)
     pg.finish()
     r = pg.result(2 & 1)
+    if root_only and rank != 0:                                    # a rank that only sends holds no gathered copy
+        ok = ok and r is None and pg.full[0] is None
+        dist.barrier()
+        q.put(bool(ok))
+        dist.destroy_process_group()
+        return
+    if not gather_traj:
+        ok = ok and r["traj"] is None
     for rr in range(world):
         ok = ok and torch.equal(r["out"][rr], torch.arange(9 * b, dtype=torch.float64).reshape(9, b) + 1000.0 * rr + 2e5)
-        ok = ok and torch.equal(r["traj"][rr], torch.arange(2 * N * b, dtype=torch.float64).reshape(2 * N, b) - 7.0 * rr)
+        if gather_traj:
+            ok = ok and torch.equal(r["traj"][rr], torch.arange(2 * N * b, dtype=torch.float64).reshape(2 * N, b) - 7.0 * rr)
         ok = ok and torch.equal(r["status"][rr], torch.full((b,), rr, dtype=torch.int32))
         ok = ok and torch.equal(r["iters"][rr], torch.arange(b, dtype=torch.int32) + 200)
     r1 = pg.result(1)                                              # the other buffer set still holds step 1
@@ -98,11 +109,12 @@ def _worker_packed(rank, world, port, b, q):
     dist.destroy_process_group()
 
 
-def test_packed_gather_two_ranks():
+@pytest.mark.parametrize("root_only,gather_traj", [(False, True), (True, True), (True, False)])
+def test_packed_gather_two_ranks(root_only, gather_traj):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + 7
-    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, 48, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + 7 + 3 * int(root_only) + int(gather_traj)
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, 48, q, root_only, gather_traj)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(2)]

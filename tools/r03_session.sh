@@ -15,5 +15,74 @@ a)
 t)   # parity tests only
   timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/r03t_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -15 $OUT/r03t_pytest.log
   ;;
+k)   # selected tests: K="expr"
+  timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "$K" > $OUT/r03k_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -25 $OUT/r03k_pytest.log
+  ;;
+d)   # deferred tails: cut sweep on every workload (no legs, no CPU / host legs)
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03d_$tag.json 2> $OUT/r03d_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03d_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["config"]["deferred_tails"] if isinstance(r["config"]["deferred_tails"], str) else {k: r["config"]["deferred_tails"][k] for k in ("tail_launches", "instances_over_the_cut_in_the_last_batch")}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for c in 0 10 12 14 16 20; do run head_c$c --steps 60 --tail-cut $c; done
+  for c in 0 12 16 20 30; do run survey_c$c --steps 30 --population survey --tail-cut $c; done
+  MPC_TAIL_PRIORITY=low run survey_c16_lowprio --steps 30 --population survey --tail-cut 16
+  MPC_TAIL_PRIORITY=normal run survey_c16_normprio --steps 30 --population survey --tail-cut 16
+  for c in 0 16 24 32 48; do run w64_c$c --steps 30 --weights-sweep --inflight 4 --tail-cut $c; done
+  for c in 0 16 24 32 48; do run w32_c$c --steps 30 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut $c; done
+  for c in 0 16 24 32; do run n25_c$c --steps 20 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4 --tail-cut $c; done
+  ;;
+e)   # deferred tails: steady state (more steps), capacity, tail waves; kernel trace of one configuration
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03e_$tag.json 2> $OUT/r03e_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03e_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["config"]["deferred_tails"] if isinstance(r["config"]["deferred_tails"], str) else {k: r["config"]["deferred_tails"][k] for k in ("tail_launches", "instances_over_the_cut_in_the_last_batch")}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  run survey_c16_s200 --steps 200 --population survey --tail-cut 16
+  run survey_c20_s200 --steps 200 --population survey --tail-cut 20
+  run survey_c20_s400 --steps 400 --population survey --tail-cut 20
+  run head_c20_s200 --steps 200 --tail-cut 20
+  run head_c0_s200 --steps 200 --tail-cut 0
+  run w32_c24_s100 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 24
+  run w32_c24_s100_i8 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 8 --tail-cut 24
+  MPC_TAIL_WAVES=512 run w32_c24_s100_w512 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 24
+  MPC_TAIL_WAVES=128 run w32_c24_s100_w128 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 24
+  run w64_c24_s100 --steps 100 --weights-sweep --inflight 4 --tail-cut 24
+  run n25_c24_s60 --steps 60 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4 --tail-cut 24
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03e_prof_w32 -o trace -- python3 $R/bench.py --steps 40 --warmup 2 --no-legs --no-cpu-baseline --no-host-leg --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 24 > $OUT/r03e_prof_w32.json 2> $OUT/r03e_prof_w32.err; echo "rocprof exit=$?" | tee -a $P
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03e_prof_survey -o trace -- python3 $R/bench.py --steps 60 --warmup 2 --no-legs --no-cpu-baseline --no-host-leg --population survey --tail-cut 20 > $OUT/r03e_prof_survey.json 2> $OUT/r03e_prof_survey.err; echo "rocprof exit=$?" | tee -a $P
+  cd $R
+  ;;
+f)   # deferred tails with several tail streams and a longer ring
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "deferred" > $OUT/r03f_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r03f_pytest.log
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03f_$tag.json 2> $OUT/r03f_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03f_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["config"]["deferred_tails"] if isinstance(r["config"]["deferred_tails"], str) else {k: r["config"]["deferred_tails"][k] for k in ("tail_launches", "instances_over_the_cut_in_the_last_batch")}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for st in 1 2 3; do for ring in 32 64; do MPC_TAIL_STREAMS=$st run survey_c20_st${st}_r$ring --steps 300 --population survey --tail-cut 20 --tail-ring $ring; done; done
+  MPC_TAIL_STREAMS=2 run survey_c16_st2_r64 --steps 300 --population survey --tail-cut 16 --tail-ring 64
+  MPC_TAIL_STREAMS=2 run head_c20_st2 --steps 200 --tail-cut 20
+  MPC_TAIL_STREAMS=2 run w32_c24_st2 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 24
+  MPC_TAIL_STREAMS=2 run w32_c20_st2 --steps 100 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut 20
+  MPC_TAIL_STREAMS=2 run w64_c24_st2 --steps 100 --weights-sweep --inflight 4 --tail-cut 24
+  MPC_TAIL_STREAMS=2 run n25_c24_st2 --steps 60 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4 --tail-cut 24
+  ;;
+b)   # the default bench line as the driver runs it
+  ( time timeout -k 10 900 python bench.py > $OUT/r03b_bench.json 2> $OUT/r03b_bench.err ) 2>&1 | tail -3 | tee -a $P; python tools/show_bench.py $OUT/r03b_bench.json | tee -a $P
+  ;;
 esac
 echo done | tee -a $P

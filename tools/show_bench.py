@@ -17,3 +17,9 @@ for p in sys.argv[1:]:
             h["solves_per_s_incl_pcie"], h["ms_per_batch"], h["matches_device_path_bitwise"], h["b1_latency_ms_median"], h["b1_kernel_ms"], h["b1_iterations"]))
     if "cpu_baseline" in r:
         print("      cpu: %.1f solves/s on 1 core; %.1f on %d cores" % (r["cpu_baseline"]["value"], r["cpu_baseline_all_cores"]["value"], r["cpu_baseline_all_cores"]["cores"]))
+    for k in ["unfiltered"] + sorted(r.get("other_configs", {})):
+        l = r.get(k) or r.get("other_configs", {}).get(k)
+        if l:
+            print("      leg %-16s %.4g solves/s  %.3f ms/batch  B %d  inflight %d  tail_cut %s  iters %.2f (max %d)  status %s" % (
+                k, l["solves_per_s"], l["ms_per_batch"], l["batch"], l["batches_in_flight"], l["tail_cut"], l["mean_iterations"], l["max_iterations"],
+                {a: b for a, b in l["status_counts"].items() if b}))
