@@ -61,6 +61,11 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="config-fast.json")
     ap.add_argument("--no-traj", action="store_true")
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64", help="f32 = MPC_PRECISION_F32 (BASELINE.json configs[4])")
+    ap.add_argument("--f32-pure", action="store_true", help="--precision f32 with MpcParams.f32_finish = 0: the pure fp32 solver of round 2 "
+                    "(tol_f32, looser tolerances) instead of fp32 iterations finished in fp64")
+    ap.add_argument("--f64-f32-start", action="store_true", help="fp64 handle with MpcParams.f64_f32_start = 1: the early iterations on the fp32 "
+                    "record, every instance finished by the fp64 solver (experimental)")
+    ap.add_argument("--switch-mu", type=float, default=0.0, help="MpcParams.mixed_switch_mu (default 2e-5)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline legs (one thread + all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive and B=1 latency measurements")
@@ -311,10 +316,11 @@ def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
 
     def leg(name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered", velocity_weights=(0.0, 1.0, 100.0), note=None,
-            tail_cut=0, steps=None):
+            tail_cut=0, steps=None, f32_pure=False):
         params = pkg.params_from_json(os.path.join(golden, config), **over)
         if f32:
             params.precision = pkg.PRECISION_F32
+            params.f32_finish = 0 if f32_pure else 1
         if args.max_iter > 0:
             params.max_iter = args.max_iter
         tdt = torch.float32 if f32 else torch.float64
@@ -348,7 +354,10 @@ def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
                                   "config-stable.json", dict(N=25, dt=0.05), 32768, "lake", False, False, True, 4, tail_cut=24, steps=40)
     legs["configs_4_share"] = leg("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, "
                                   "per-instance weight sweep (epsi / v incl. 0 / delta / a)", "config-fast.json", {}, 131072, "lake", True, True, False,
-                                  4, tail_cut=24, steps=60)
+                                  4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance "
+                                  "finished in fp64 (tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")
+    legs["configs_4_share_pure_fp32"] = leg("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), "
+                                            "deferred tails", "config-fast.json", {}, 131072, "lake", True, True, False, 4, tail_cut=24, steps=60, f32_pure=True)
     return legs
 
 
@@ -413,6 +422,10 @@ def main():
     f32 = args.precision == "f32"
     if f32:
         params.precision = pkg.PRECISION_F32
+        params.f32_finish = 0 if args.f32_pure else 1
+    params.f64_f32_start = 1 if args.f64_f32_start else 0
+    if args.switch_mu > 0:
+        params.mixed_switch_mu = args.switch_mu
     if args.max_iter > 0:
         params.max_iter = args.max_iter
     cuts = [int(c) for c in args.pass_cuts.split(",") if c.strip()][:4]
@@ -513,6 +526,8 @@ def main():
                    "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
                    "termination_polish": bool(params.polish), "bound_relax_factor": params.bound_relax_factor, "pass_cuts": cuts,
+                   "mixed_precision": ("fp32 iterations to mu = %g, every instance finished in fp64" % params.mixed_switch_mu) if ((f32 and params.f32_finish) or
+                                                                                                                                (not f32 and params.f64_f32_start)) else "no",
                    "deferred_tails": summary.get("tails", "off"), "tail_cut": pipe.tail,
                    # the generator redraws instances the reference's own road model does not hold for (scenarios.py); the
                    # `unfiltered` leg below is the same workload without that

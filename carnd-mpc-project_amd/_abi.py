@@ -71,7 +71,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
            "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device",
-           "mpc_last_batch_id", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info"]
+           "mpc_last_batch_id", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
 
 _lib = None
 
@@ -116,6 +116,7 @@ def library():
     L.mpc_abi_version.restype = C.c_int
     L.mpc_solve_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9 + [C.c_void_p]
     L.mpc_solve_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9
+    L.mpc_solve_batch_host_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9
     L.mpc_solve_batch_device_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [DP] * 9 + [C.c_void_p]
     L.mpc_synchronize.argtypes = [C.c_void_p]
     L.mpc_get_stats.argtypes = [C.c_void_p, C.POINTER(MpcBatchStats)]

@@ -1362,12 +1362,20 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   /* the interior-point iteration                                         */
   /* ------------------------------------------------------------------ */
-  enum { MPC_RUNNING = -1 };
+  enum { MPC_RUNNING = -1, MPC_PROMOTE = -2 };   /* PROMOTE: the fp32 phase of a mixed-precision solve hands the instance to fp64 */
   enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
   enum { kMaxPolish = 6 };
+  enum { kPromoteIterCap = 40 };   /* mixed precision: iterations after which the fp32 phase hands an instance over whatever its barrier parameter */
   /* state of the interior-point loop (see step()) */
   int phase, iter, n_polish;
   bool ls_start, tiny;
+  /* Mixed precision across phases (MpcParams.f32_finish / f64_f32_start): an fp32 solver with promote_mu > 0 stops being
+   * responsible for an instance as soon as its barrier parameter is about to go below promote_mu (or the instance has met
+   * tol_f32, or its line search has run out of single precision): step() returns MPC_PROMOTE at a pass boundary, the
+   * instance is parked (park()), and an fp64 solver takes the iterate over (unpark() + promoted()): it re-evaluates the
+   * point in fp64 and carries on with the same state machine to tol and the polish. */
+  R promote_mu = R(0.0);
+  bool keep_theta = false;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   R out_prev;     /* the same of the step before (fp32 wants two quiet steps in a row) */
   R tol, out_tol;  /* "tol" of this precision (MpcParams.tol or tol_f32) and the polish's step tolerance */
@@ -1423,6 +1431,13 @@ struct Solver {
     iters = iter; phase = PH_DIR;
   }
 
+  /* after unpark() of an instance that another precision parked with MPC_PROMOTE: evaluate the point as this solver sees it
+   * (one trial sweep with alpha = 0), then carry on; theta_max / theta_min stay those of the start point */
+  MPC_HD void promoted() {
+    phase = PH_EVAL0; keep_theta = true; ls_start = false; nf = 0; n_polish = 0; out_step = out_prev = IC::huge;
+    alpha = alpha_l = alpha_z = dw_cur = R(0.0);
+  }
+
   MPC_HD void begin(bool ls) {
     cur = 0; mu = IC::mu_init; tau = mpc_max(IC::tau_min, R(1.0) - mu); nf = 0; iters = 0; n_reg = 0; lsm = false;
     /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
@@ -1442,6 +1457,7 @@ struct Solver {
    * rounding into the dual residual, slacks of a few ulp cannot shrink), so a point whose optimality error is within
    * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
   MPC_HD int line_search_failed() const {
+    if (promote_mu > R(0.0)) return MPC_PROMOTE;   /* out of step length in single precision: the iterate goes on in fp64 */
     if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
     /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
     if (n_polish > 0 && kkt_error(E, R(0.0)) <= tol) return MPC_STATUS_SUCCESS;
@@ -1467,6 +1483,9 @@ struct Solver {
         iters = iter;
         const R E0 = kkt_error(E, R(0.0));
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
+        /* as far as this precision is asked to go -- or an instance that is taking long: the stragglers (steps of a few per
+         * cent against a bound for dozens of iterations) are where the noise of fp32 steps costs most; they go on in fp64 */
+        if (promote_mu > R(0.0) && (E0 <= tol || iter >= kPromoteIterCap)) return MPC_PROMOTE;
         if (E0 <= tol) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
@@ -1487,6 +1506,7 @@ struct Solver {
           tau = mpc_max(IC::tau_min, R(1.0) - mu);
           nf = 0;
         }
+        if (promote_mu > R(0.0) && mu <= promote_mu) return MPC_PROMOTE;   /* the barrier problems below are the other solver's */
 #if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
         printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
                E.dinf, E.cmin, E.cmax, mu, E0, nf);
@@ -1501,7 +1521,7 @@ struct Solver {
         if (lsm) { okb = false; break; }
         if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
         else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
-        if (dw > IC::dw_max || ++tries > 100) return MPC_STATUS_LINESEARCH;
+        if (dw > IC::dw_max || ++tries > 100) return promote_mu > R(0.0) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH;
       }
       if (okb) forward();
       dw_cur = dw;
@@ -1525,9 +1545,10 @@ struct Solver {
     R lmax;
     const EvalR T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
     if (phase == PH_EVAL0) {
-      E = T; cur = 1;
+      E = T; cur = 1 - cur;                       /* (a fresh start evaluates slot 0 into slot 1) */
       if (!E.ok) return MPC_STATUS_NUMERIC;
-      theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta);
+      if (!keep_theta) { theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta); }
+      keep_theta = false;
       phase = ls_start ? PH_LS : PH_DIR;
       return MPC_RUNNING;
     }
@@ -1620,6 +1641,19 @@ struct Solver {
     }
   }
 };
+
+/* The iterate record of one stage carried from one precision's layout to the other's (s 6, u 2, lam 6, bound duals 4 + 4;
+ * the fp32 record pads the multipliers): get(f) reads field f of the source record, put(f, v) writes the destination's. */
+template <class RS, class RD, class Get, class Put>
+MPC_HD void convert_iterate_record(Get get, Put put) {
+  using FS = Fields<RS>;
+  using FD = Fields<RD>;
+  MPC_UNROLL
+  for (int i = 0; i < 6; i++) { put(FD::F_S + i, (RD)get(FS::F_S + i)); put(FD::F_LAM + i, (RD)get(FS::F_LAM + i)); }
+  put(FD::F_U, (RD)get(FS::F_U)); put(FD::F_U + 1, (RD)get(FS::F_U + 1));
+  MPC_UNROLL
+  for (int b = 0; b < 4; b++) { put(FD::F_ZL + b, (RD)get(FS::F_ZL + b)); put(FD::F_ZU + b, (RD)get(FS::F_ZU + b)); }
+}
 
 /* One instance, end to end (used by the test-only host build; the device kernel
  * drives Solver directly so that outputs go straight to their HBM arrays). */

@@ -110,6 +110,12 @@ struct MpcPhase {
   const void *src_ws;       /* resume: workspace of the previous phase */
   int32_t pass_cut;         /* park after this many passes in this phase (0 = never) */
   int32_t resume;           /* 0 = first phase (fresh instances), 1 = takes parked ones */
+  /* Mixed precision across phases (MpcParams.f32_finish, f64_f32_start): a phase with promote_out != 0 runs the fp32 solver
+   * with Solver::promote_mu set and parks every instance that returns MPC_PROMOTE; the next phase (promote_in != 0) is the
+   * fp64 solver resuming from that list: the parked iterate, in the fp32 record layout of src_ws (tiles of src_tile_reals
+   * floats), is converted field by field, the point is re-evaluated in fp64 and the solve goes on to tol and the polish. */
+  int32_t promote_out, promote_in;
+  int64_t src_tile_reals;
   /* Hand-over policy.  Writing a finished instance out and fetching the next one (set-up, start point: 270 stores) is
    * divergent code that the whole wave pays for, ~4 us per event against ~80 us per pass, and with 64 lanes finishing at
    * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
@@ -133,11 +139,20 @@ struct MpcPhase {
 
 /* OCC = waves per SIMD the register allocation is held to: the fp64 solver needs ~380 registers (1); the fp32 solver
  * fits 256 with a few spilled values (2), or runs unconstrained (1) */
-template <bool STAGING, class R, int OCC>
+/* what Solver::unpack writes through when the arrays at the ABI are of another type than the solver's reals */
+template <class RIO, class R> struct OutRef {
+  RIO *p;
+  __device__ __host__ void operator=(R v) const { *p = (RIO)v; }
+};
+
+/* RIO: the type of the arrays at the ABI (inputs, outputs); R: the solver's.  They differ only in the fp64 phase of a
+ * mixed-precision solve on an MPC_PRECISION_F32 handle (RIO = float, R = double).  RSRC: the reals of the workspace a
+ * promote_in phase takes its iterates from. */
+template <bool STAGING, class R, int OCC, class RIO = R, class RSRC = RIO>
 __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
-    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
-    const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
-    const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
+    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const RIO *__restrict__ state,
+    const RIO *__restrict__ coeffs, const RIO *__restrict__ yaw_lo, const RIO *__restrict__ yaw_hi,
+    const RIO *__restrict__ weights, RIO *__restrict__ out, RIO *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, R *__restrict__ wsbase,
     const int64_t tile_reals, const MpcPhase T) {
   extern __shared__ double smem[];
@@ -184,6 +199,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   ws.lane = threadIdx.x;
   ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
+  if (T.promote_out) S.promote_mu = (R)P.mixed_switch_mu;
   int64_t i = 0;
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
   bool queue_full = false;                       /* deferred tails: the batch's queue slot has no room left */
@@ -196,10 +212,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
       if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait) {
         waited = 0;
         if (fin) {
-          R *o = out + i;
-          R *t = traj ? traj + i : nullptr;
+          RIO *o = out + i;
+          RIO *t = traj ? traj + i : nullptr;
           const int64_t l = ldo;
-          S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
+          S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, traj != nullptr,
+                   (R)yaw_lo[i], (R)yaw_hi[i]);
           status[i] = fin_status;
           if (iters) iters[i] = S.iters + it_total;
           fin = false;
@@ -211,32 +228,50 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
             i = T.resume ? (int64_t)T.in_inst[pos] : pos;
             R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
-            for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+            for (int q = 0; q < 6; q++) st[q] = (R)state[q * ld + i];
 #pragma unroll
-            for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+            for (int q = 0; q < MPC_NCOEF; q++) cf[q] = (R)coeffs[q * ld + i];
             if (weights) {
 #pragma unroll
-              for (int q = 0; q < MPC_NW; q++) w[q] = weights[q * ld + i];
+              for (int q = 0; q < MPC_NW; q++) w[q] = (R)weights[q * ld + i];
             } else {
 #pragma unroll
               for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
             }
-            const int s0 = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, !T.resume);
+            const int s0 = S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, !T.resume);
             if (T.resume) {
               /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
               const double *pk = T.in_park + pos;
               const int64_t lp = T.ld_park;
               S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
               const int src = T.in_src[pos];
-              WS wsrc = ws;
-              wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
-              wsrc.lane = src & 63;
               const int I = S.cur ? FL::IT1 : FL::IT0;
-              for (int k = 0; k < P.N - 1; ++k) {
-                R rec[FL::IT_SZ];
+              if (T.promote_in) {
+                /* the iterate as the fp32 phase left it: its record layout, its tile size; then this solver's own evaluation */
+                using FS = mpc::Fields<RSRC>;
+                mpc::TiledWorkspace<false, RSRC> wsrc;
+                wsrc.tile = (typename mpc::TiledWorkspace<false, RSRC>::greal *)((const RSRC *)T.src_ws + (int64_t)(src >> 6) * T.src_tile_reals);
+                wsrc.lane = src & 63; wsrc.lbuf = nullptr;
+                const int Is = S.cur ? FS::IT1 : FS::IT0;
+                for (int k = 0; k < P.N - 1; ++k) {
+                  R rec[FL::IT_SZ] = {};
+                  mpc::convert_iterate_record<RSRC, R>([&](int f) { return (RSRC)wsrc.it(k, Is, f); }, [&](int f, R v) { rec[f] = v; });
+                  ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+                  /* the re-evaluation is a trial sweep with step length 0: it multiplies whatever the direction record holds */
+                  const R zero[FL::D_N] = {};
+                  ws.template store_run<FL::F_D, FL::D_N>(k, 0, zero);
+                }
+                S.promoted();
+              } else {
+                WS wsrc = ws;
+                wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
+                wsrc.lane = src & 63;
+                for (int k = 0; k < P.N - 1; ++k) {
+                  R rec[FL::IT_SZ];
 #pragma unroll
-                for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
-                ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+                  for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
+                  ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+                }
               }
               passes = 0; have = true;
             } else if (s0 == MPC_STATUS_SUCCESS) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
@@ -250,7 +285,16 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     if (have) {
       const int r = S.step();
       ++passes;
-      if (r != SV::MPC_RUNNING) {
+      if (r == SV::MPC_PROMOTE) {
+        /* mixed precision: this phase has taken the instance as far as it is asked to; the next phase's solver takes over */
+        const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
+        T.out_inst[pos] = (int32_t)i;
+        T.out_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+        double *pk = T.out_park + pos;
+        const int64_t lp = T.ld_park;
+        S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
+        have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
+      } else if (r != SV::MPC_RUNNING) {
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
           attempt = 1; it_total += S.iters;
@@ -609,6 +653,9 @@ struct MpcHandle {
   bool staging = true;
   int lds_lanes = 0;       /* instances per workgroup of the LDS-resident kernel (0: N too large for it, or MPC_LDS=0) */
   int64_t lds_max_batch = 0;   /* launches up to this size take the LDS-resident kernel: lds_lanes x number of CUs */
+  bool mixed = false;      /* two phases per solve: fp32 up to MpcParams.mixed_switch_mu, then fp64 to tol (f32_finish on an F32 handle,
+                            * f64_f32_start on an F64 handle) */
+  int64_t ws_stride_f32 = 0, ws_stride_f64 = 0;   /* reals per wavefront tile of either record layout */
   bool occ2 = false;       /* fp32: MPC_F32_OCC=2 selects the build held to 256 registers (two waves per SIMD, ~110 spill reloads per
                             * pass); the unconstrained build (296 registers, one wave per SIMD) measured 7 % faster on the final code */
   int64_t io_stride = 0;   /* leading dimension of the handle's own staging arrays */
@@ -618,7 +665,7 @@ struct MpcHandle {
   /* staging of the host-pointer entry point: ONE device block and its pinned host mirror, rows with a per-call
    * leading dimension: in = state[6] coeffs[5] ylo yhi weights[12] (25 rows) | out = out[9] traj[2N] | one row holding
    * status and iters (int32 each) -- so a call is one copy in, the launch, one copy out */
-  double *d_io = nullptr, *h_io = nullptr;
+  void *d_io = nullptr, *h_io = nullptr;
   unsigned long long *d_stats = nullptr;   /* [8] statistics of the last batch (mpc_stats_kernel) */
   hipEvent_t ev_stats = nullptr;
   bool have_stats = false;
@@ -763,6 +810,16 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   } else MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
+  h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true) * 64;
+  h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false) * 64;
+  h->mixed = f32 ? p->f32_finish != 0 : p->f64_f32_start != 0;
+  if (const char *e = getenv("MPC_MIXED")) h->mixed = atoi(e) != 0;
+  if (h->mixed) {
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1, float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1, double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1, double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+    MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+  }
   {
     /* LDS-resident kernel: as many instances per workgroup as 160 KB hold (32, 16 or 8); one workgroup per CU */
     const int64_t per_inst = mpc::workspace_fields_per_instance(p->N, f32) * (int64_t)(f32 ? sizeof(float) : sizeof(double));
@@ -823,6 +880,9 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
   int rc = validate_params(p);
   if (rc != MPC_OK) return rc;
+  if ((p->precision == MPC_PRECISION_F32 ? p->f32_finish != 0 : p->f64_f32_start != 0) != h->mixed && !getenv("MPC_MIXED")) {
+    g_last_error = "f32_finish / f64_f32_start cannot change on a live handle (they decide the workspaces)"; return MPC_ERR_INVALID;
+  }
   if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
   if (h->tail_ready && (p->tail_ring != h->params.tail_ring || p->tail_capacity != h->params.tail_capacity)) {
     g_last_error = "tail_ring and tail_capacity cannot change once the tail queue exists"; return MPC_ERR_INVALID;
@@ -1083,6 +1143,54 @@ extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
   return MPC_OK;
 }
 
+/* Mixed precision across phases: phase 0 = the fp32 solver on the handle's fp32 workspace, parking every instance at
+ * MPC_PROMOTE; phase 1 = the fp64 solver resuming all of them on the fp64 workspace.  RIO is the handle's own precision
+ * (the type at the ABI).  Instances the fp32 phase finishes itself (rejected at set-up, not-a-number, iteration cap) are
+ * final after phase 0. */
+template <class RIO>
+static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const RIO *state, const RIO *coeffs, const RIO *yaw_lo,
+                        const RIO *yaw_hi, const RIO *weights, RIO *out, RIO *traj, int32_t *status, int32_t *iters, hipStream_t s,
+                        bool with_stats) {
+  const int64_t tiles = h->io_stride / 64;
+  if (!h->ws2) {
+    /* h->ws holds the handle's own layout; the phases need one workspace of each */
+    const size_t other = sizeof(RIO) == 4 ? (size_t)h->ws_stride_f64 * tiles * sizeof(double) : (size_t)h->ws_stride_f32 * tiles * sizeof(float);
+    MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, other));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
+  }
+  float *ws32 = sizeof(RIO) == 4 ? (float *)h->ws : (float *)h->ws2;
+  double *ws64 = sizeof(RIO) == 4 ? (double *)h->ws2 : (double *)h->ws;
+  int32_t *it_out = iters ? iters : h->d_iters;
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, kCounterInts * sizeof(int32_t), s));
+  MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
+  const unsigned waves = (unsigned)((B + kBlock - 1) / kBlock);
+  MpcPhase T;
+  memset(&T, 0, sizeof(T));
+  T.take = h->d_counter; T.n_out = h->d_counter + 1;
+  T.out_inst = h->d_list; T.out_src = h->d_list + h->io_stride; T.out_park = h->d_park; T.ld_park = h->io_stride;
+  T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+  T.promote_out = 1;
+  hipLaunchKernelGGL((mpc_solve_kernel<true, float, 1, RIO, RIO>), dim3(waves), dim3(kBlock), staging_lds_bytes<float>(), s, h->params, B, ld, ldo, state,
+                     coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws32, h->ws_stride_f32, T);
+  MPC_HIP_CHECK(hipGetLastError());
+  MpcPhase U;
+  memset(&U, 0, sizeof(U));
+  U.take = h->d_counter + 2; U.n_out = h->d_counter + 3; U.n_in = h->d_counter + 1;
+  U.in_inst = h->d_list; U.in_src = h->d_list + h->io_stride; U.in_park = h->d_park; U.ld_park = h->io_stride;
+  U.out_inst = h->d_list + 2 * h->io_stride; U.out_src = h->d_list + 3 * h->io_stride; U.out_park = h->d_park + (int64_t)kParkRows * h->io_stride;
+  U.src_ws = ws32; U.src_tile_reals = h->ws_stride_f32;
+  U.resume = 1; U.promote_in = 1;
+  U.refill_min = h->refill_min; U.refill_wait = h->refill_wait;
+  hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
+                     coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
+  MPC_HIP_CHECK(hipGetLastError());
+  MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  if (with_stats) return record_stats(h, B, status, it_out, s);
+  return MPC_OK;
+}
+
 /* the launch; ld = leading dimension of the inputs, ldo = of out/traj */
 template <class R>
 static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs,
@@ -1106,6 +1214,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
+  if (h->mixed) return launch_mixed<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s, with_stats);
   const bool defer = may_defer && h->params.tail_cut > 0 && B >= h->tail_min_batch && !(h->lds_lanes > 0 && B <= h->lds_max_batch);
   const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
   MpcHandle::TailSlot *ts = nullptr;
@@ -1157,6 +1266,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
    * reads list (p - 1) & 1 and the workspace of phase p - 1; every phase has the grid of the first (see MpcPhase) */
   for (int p = 0; p <= n_cuts; ++p) {
     MpcPhase T;
+    memset(&T, 0, sizeof(T));          /* every switch a phase does not set is off */
     const int wr = p & 1, rd = wr ^ 1;
     T.take = h->d_counter + 2 * p;
     T.n_out = h->d_counter + 2 * p + 1;
@@ -1342,11 +1452,15 @@ extern "C" int mpc_synchronize(MpcHandle *h) {
   return MPC_OK;
 }
 
-extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *state,
-                                    const double *coeffs, const double *yaw_lo, const double *yaw_hi,
-                                    const double *weights, double *out, double *traj, int32_t *status,
-                                    int32_t *iters) {
+/* host pointers: one copy in, the launch(es), one copy out, on the handle's own stream; R = the handle's precision */
+template <class R>
+static int solve_host(MpcHandle *h, int64_t B, int64_t ld, const R *state, const R *coeffs, const R *yaw_lo, const R *yaw_hi,
+                      const R *weights, R *out, R *traj, int32_t *status, int32_t *iters) {
   if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if ((h->params.precision == MPC_PRECISION_F32) != (sizeof(R) == 4)) {
+    g_last_error = "this handle was created with the other precision (mpc_solve_batch_host for fp64 handles, mpc_solve_batch_host_f32 for MPC_PRECISION_F32)";
+    return MPC_ERR_INVALID;
+  }
   if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
   if (B == 0) { h->last_B = 0; h->have_stats = false; return MPC_OK; }
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
@@ -1354,37 +1468,52 @@ extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const d
   const int N = h->params.N;
   const int64_t S = h->io_stride;
   constexpr int kInRows = 6 + MPC_NCOEF + 2 + MPC_NW;              /* 25 */
-  const int kOutRows = MPC_NOUT + 2 * N + 1;                       /* out, traj, one row of status|iters (N is fixed per handle) */
+  constexpr int kIntRows = sizeof(R) == 8 ? 1 : 2;                 /* status and iters: 2 x int32 per instance */
+  const int kOutRows = MPC_NOUT + 2 * N + kIntRows;                /* out, traj, status|iters (N is fixed per handle) */
   if (!h->d_io) {
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_io, sizeof(double) * (kInRows + kOutRows) * S));
-    MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_io, sizeof(double) * (kInRows + kOutRows) * S, hipHostMallocDefault));
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_io, sizeof(R) * (kInRows + kOutRows) * S));
+    MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_io, sizeof(R) * (kInRows + kOutRows) * S, hipHostMallocDefault));
   }
-  /* rows packed with leading dimension L (B rounded up to 8: 64-byte rows), so each direction is ONE copy */
-  const int64_t L = (B + 7) / 8 * 8;
+  /* rows packed with leading dimension L (B rounded up to 16: 64-byte rows), so each direction is ONE copy */
+  const int64_t L = (B + 15) / 16 * 16;
   const int in_rows = weights ? kInRows : kInRows - MPC_NW;
-  const int out_rows = MPC_NOUT + (traj ? 2 * N : 0) + 1;
-  double *hi = h->h_io, *ho = h->h_io + kInRows * S;
-  double *di = h->d_io, *d_oblk = h->d_io + kInRows * S;
-  for (int q = 0; q < 6; q++) memcpy(hi + q * L, state + q * ld, sizeof(double) * B);
-  for (int q = 0; q < MPC_NCOEF; q++) memcpy(hi + (6 + q) * L, coeffs + q * ld, sizeof(double) * B);
-  memcpy(hi + 11 * L, yaw_lo, sizeof(double) * B);
-  memcpy(hi + 12 * L, yaw_hi, sizeof(double) * B);
-  if (weights) for (int q = 0; q < MPC_NW; q++) memcpy(hi + (13 + q) * L, weights + q * ld, sizeof(double) * B);
+  const int out_rows = MPC_NOUT + (traj ? 2 * N : 0) + kIntRows;
+  R *hi = (R *)h->h_io, *ho = (R *)h->h_io + kInRows * S;
+  R *di = (R *)h->d_io, *d_oblk = (R *)h->d_io + kInRows * S;
+  for (int q = 0; q < 6; q++) memcpy(hi + q * L, state + q * ld, sizeof(R) * B);
+  for (int q = 0; q < MPC_NCOEF; q++) memcpy(hi + (6 + q) * L, coeffs + q * ld, sizeof(R) * B);
+  memcpy(hi + 11 * L, yaw_lo, sizeof(R) * B);
+  memcpy(hi + 12 * L, yaw_hi, sizeof(R) * B);
+  if (weights) for (int q = 0; q < MPC_NW; q++) memcpy(hi + (13 + q) * L, weights + q * ld, sizeof(R) * B);
   hipStream_t s = h->stream;
-  MPC_HIP_CHECK(hipMemcpyAsync(di, hi, sizeof(double) * in_rows * L, hipMemcpyHostToDevice, s));
-  double *d_o = d_oblk, *d_t = d_o + MPC_NOUT * L;
-  int32_t *d_st = (int32_t *)(d_o + (out_rows - 1) * L), *d_it = d_st + L;
-  int rc = launch_solve<double>(h, B, L, L, di, di + 6 * L, di + 11 * L, di + 12 * L, weights ? di + 13 * L : nullptr, d_o,
-                        traj ? d_t : nullptr, d_st, d_it, (void *)s);
+  MPC_HIP_CHECK(hipMemcpyAsync(di, hi, sizeof(R) * in_rows * L, hipMemcpyHostToDevice, s));
+  R *d_o = d_oblk, *d_t = d_o + MPC_NOUT * L;
+  int32_t *d_st = (int32_t *)(d_o + (out_rows - kIntRows) * L), *d_it = d_st + L;
+  int rc = launch_solve<R>(h, B, L, L, di, di + 6 * L, di + 11 * L, di + 12 * L, weights ? di + 13 * L : nullptr, d_o,
+                           traj ? d_t : nullptr, d_st, d_it, (void *)s);
   if (rc != MPC_OK) return rc;
-  MPC_HIP_CHECK(hipMemcpyAsync(ho, d_o, sizeof(double) * out_rows * L, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(ho, d_o, sizeof(R) * out_rows * L, hipMemcpyDeviceToHost, s));
   MPC_HIP_CHECK(hipStreamSynchronize(s));
-  for (int q = 0; q < MPC_NOUT; q++) memcpy(out + q * ld, ho + q * L, sizeof(double) * B);
-  if (traj) for (int q = 0; q < 2 * N; q++) memcpy(traj + q * ld, ho + (MPC_NOUT + q) * L, sizeof(double) * B);
-  const int32_t *h_st = (const int32_t *)(ho + (out_rows - 1) * L);
+  for (int q = 0; q < MPC_NOUT; q++) memcpy(out + q * ld, ho + q * L, sizeof(R) * B);
+  if (traj) for (int q = 0; q < 2 * N; q++) memcpy(traj + q * ld, ho + (MPC_NOUT + q) * L, sizeof(R) * B);
+  const int32_t *h_st = (const int32_t *)(ho + (out_rows - kIntRows) * L);
   memcpy(status, h_st, sizeof(int32_t) * B);
   if (iters) memcpy(iters, h_st + L, sizeof(int32_t) * B);
   return MPC_OK;
+}
+
+extern "C" int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *state,
+                                    const double *coeffs, const double *yaw_lo, const double *yaw_hi,
+                                    const double *weights, double *out, double *traj, int32_t *status,
+                                    int32_t *iters) {
+  return solve_host<double>(h, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters);
+}
+
+extern "C" int mpc_solve_batch_host_f32(MpcHandle *h, int64_t B, int64_t ld, const float *state,
+                                        const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                                        const float *weights, float *out, float *traj, int32_t *status,
+                                        int32_t *iters) {
+  return solve_host<float>(h, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters);
 }
 
 extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {

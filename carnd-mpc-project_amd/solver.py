@@ -160,18 +160,20 @@ class BatchedMPC:
 
     # -- host path (numpy arrays; copies through PCIe) ------------------------
     def solve_numpy(self, state, coeffs, yaw_lo, yaw_hi, weights=None, want_traj=False):
-        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        """Host arrays through mpc_solve_batch_host (float64), or mpc_solve_batch_host_f32 for an MPC_PRECISION_F32 handle."""
+        dt = np.float32 if self.f32 else np.float64
+        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=dt))
         state, coeffs, yaw_lo, yaw_hi = f(state), f(coeffs), f(yaw_lo), f(yaw_hi)
         B = state.shape[1]
         assert state.shape == (6, B) and coeffs.shape == (5, B) and yaw_lo.shape == (B,) and yaw_hi.shape == (B,)
         if weights is not None:
             weights = f(weights)
             assert weights.shape == (_abi.NW, B)
-        out = np.empty((_abi.NOUT, B)); status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
-        traj = np.empty((2 * self.N, B)) if want_traj else None
+        out = np.empty((_abi.NOUT, B), dtype=dt); status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        traj = np.empty((2 * self.N, B), dtype=dt) if want_traj else None
         p = lambda a: a.ctypes.data if a is not None else None
-        check(library().mpc_solve_batch_host(self._h, B, B, p(state), p(coeffs), p(yaw_lo), p(yaw_hi), p(weights),
-                                             p(out), p(traj), p(status), p(iters)), "mpc_solve_batch_host")
+        fn = library().mpc_solve_batch_host_f32 if self.f32 else library().mpc_solve_batch_host
+        check(fn(self._h, B, B, p(state), p(coeffs), p(yaw_lo), p(yaw_hi), p(weights), p(out), p(traj), p(status), p(iters)), "mpc_solve_batch_host")
         return {"out": out, "status": status, "iters": iters, "traj": traj}
 
     # -- deferred tails (MpcParams.tail_cut > 0, include/mpc_amd.h) -------------

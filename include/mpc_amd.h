@@ -208,6 +208,11 @@ int mpc_solve_batch_host(MpcHandle *h, int64_t B, int64_t ld, const double *stat
                          const double *coeffs, const double *yaw_lo, const double *yaw_hi,
                          const double *weights, double *out, double *traj, int32_t *status,
                          int32_t *iters);
+/* The same for an MPC_PRECISION_F32 handle (float arrays). */
+int mpc_solve_batch_host_f32(MpcHandle *h, int64_t B, int64_t ld, const float *state,
+                             const float *coeffs, const float *yaw_lo, const float *yaw_hi,
+                             const float *weights, float *out, float *traj, int32_t *status,
+                             int32_t *iters);
 /* ---- the caller of the path: MPC::run() for a batch -------------
  * Pre-processing (waypoints to the vehicle frame, adaptive polynomial fit, cte0/epsi0, yaw bounds,
  * speed tables: src/control/MPC.cpp:329-356), the solve, and the post-processing (steering adjustment,

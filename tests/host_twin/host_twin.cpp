@@ -168,3 +168,68 @@ extern "C" int mpc_host_twin_solve_reparked_f32(const MpcParams *p, int64_t B, i
                                                 int32_t *was_parked) {
   return solve_parked_t<float>(p, B, ld, pass_cut, 1, state, coeffs, yaw_lo, yaw_hi, weights, out, status, iters, was_parked);
 }
+
+
+/* Mixed precision across phases, replayed on the host exactly as the device does it (MpcParams.f32_finish): the fp32 solver
+ * runs until it returns MPC_PROMOTE, the instance is parked, an fp64 solver unparks it on its own workspace (iterate record
+ * converted field by field), re-evaluates the point and finishes.  fp32 in and out.  iters_f32[i]: iterations of the fp32 phase. */
+extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t ld, const float *state, const float *coeffs,
+                                         const float *yaw_lo, const float *yaw_hi, const float *weights, float *out, float *traj,
+                                         int32_t *status, int32_t *iters, int32_t *iters_f32) {
+  if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
+  const int N = p->N, M = N - 1;
+  using SF = mpc::Solver<mpc::HostWorkspace<float>, float>;
+  using SD = mpc::Solver<mpc::HostWorkspace<double>, double>;
+  using FF = mpc::Fields<float>;
+  using FD = mpc::Fields<double>;
+  std::vector<float> wsf((size_t)M * FF::STAGE_SZ);
+  std::vector<double> wsd((size_t)M * FD::STAGE_SZ);
+  for (int64_t i = 0; i < B; i++) {
+    float st[6], cf[MPC_NCOEF], w[MPC_NW];
+    double std_[6], cfd[MPC_NCOEF], wd[MPC_NW], park[SF::PARK_N];
+    for (int q = 0; q < 6; q++) { st[q] = state[q * ld + i]; std_[q] = st[q]; }
+    for (int q = 0; q < MPC_NCOEF; q++) { cf[q] = coeffs[q * ld + i]; cfd[q] = cf[q]; }
+    for (int q = 0; q < MPC_NW; q++) { w[q] = weights ? weights[q * ld + i] : (float)p->weights[q]; wd[q] = weights ? (double)weights[q * ld + i] : p->weights[q]; }
+    SF A(*p, mpc::HostWorkspace<float>{wsf.data()});
+    SD D(*p, mpc::HostWorkspace<double>{wsd.data()});
+    int s = A.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0;
+    bool in_double = false;
+    if (iters_f32) iters_f32[i] = 0;
+    if (s == MPC_STATUS_SUCCESS) {
+      A.promote_mu = (float)p->mixed_switch_mu;
+      A.begin(true);
+      for (;;) {
+        const int r = in_double ? D.step() : A.step();
+        if (r == SF::MPC_RUNNING) continue;
+        if (r == SF::MPC_PROMOTE) {
+          A.park([&park](int q) -> double & { return park[q]; }, attempt, it_total);
+          if (iters_f32) iters_f32[i] = A.iter + it_total;
+          (void)D.setup(std_, cfd, (double)yaw_lo[i], (double)yaw_hi[i], wd, false);
+          D.unpark([&park](int q) -> double { return park[q]; }, attempt, it_total);
+          const int Is = A.cur ? FF::IT1 : FF::IT0, Id = D.cur ? FD::IT1 : FD::IT0;
+          for (int k = 0; k < M; k++)
+            mpc::convert_iterate_record<float, double>([&](int f) { return A.ws.it(k, Is, f); }, [&](int f, double v) { D.ws.it(k, Id, f) = v; });
+          D.promoted();
+          in_double = true;
+          continue;
+        }
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+          attempt = 1;
+          if (in_double) { it_total += D.iters; D.start_point(); D.begin(false); }
+          else { it_total += A.iters; A.start_point(); A.begin(false); }
+          continue;
+        }
+        s = r;
+        break;
+      }
+    }
+    float *o = out + i;
+    float *t = traj ? traj + i : nullptr;
+    struct Ref { float *q; void operator=(double v) { *q = (float)v; } void operator=(float v) { *q = v; } };
+    if (in_double) D.unpack([o, ld](int q) { return Ref{o + q * ld}; }, [t, ld](int q) { return Ref{t + q * ld}; }, traj != nullptr, (double)yaw_lo[i], (double)yaw_hi[i]);
+    else A.unpack([o, ld](int q) { return Ref{o + q * ld}; }, [t, ld](int q) { return Ref{t + q * ld}; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
+    status[i] = s;
+    if (iters) iters[i] = (in_double ? D.iters : A.iters) + it_total;
+  }
+  return MPC_OK;
+}

@@ -76,8 +76,8 @@ def test_soak_whole_batches_against_the_oracle(pkg, golden_dir, waypoints):
 
 
 def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
-    """BASELINE.json configs[4]'s shape: MPC_PRECISION_F32 with per-instance weights, every instance of a 65 536-batch against
-    the fp64 oracle, stated fp32 tolerances (helpers.F32_TOL_*), every status accounted for."""
+    """BASELINE.json configs[4]'s shape: MPC_PRECISION_F32 (fp32 phase + fp64 finish) with per-instance weights, every instance of a
+    batch against the fp64 oracle at the stated tolerances (helpers.F32_TOL_*: 1e-3 / 1e-3 / 1e-3 / 1e-2 m), same status as the oracle."""
     import torch
     dev = torch.device("cuda:0")
     scale, workers = _scale(), _workers()
@@ -85,7 +85,7 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
     params.precision = pkg.PRECISION_F32
     b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=111)
-    w = pkg.scenarios.weight_sweep(B, params, seed=161)
+    w = pkg.scenarios.weight_sweep(B, params, seed=161, velocity_weights=(0.0, 1.0, 100.0))     # SURVEY 8d Config 5, velocity weight 0 included
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=torch.float32)
     with pkg.BatchedMPC(params, B, device=0) as mpc:
         r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w), want_traj=True)
@@ -104,8 +104,7 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
     print(json.dumps(row))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(row, open("gpurun_out/soak_f32.json", "w"), indent=1)
-    assert (ref["status"] == 0).all()
-    assert (got["status"] != 0).sum() <= max(2, B // 20000), row          # reported, never silent: the device's own count is in the row
+    assert np.array_equal(got["status"], ref["status"]), row             # an instance ends with the status the fp64 oracle gives it
     assert d[6].max() <= F32_TOL_STEER and d[7].max() <= F32_TOL_ACCEL and d[:6].max() <= F32_TOL_STATE and dt_.max() <= F32_TOL_TRAJ and dc.max() <= F32_TOL_COST_REL, row
 
 

@@ -84,5 +84,25 @@ PY
 b)   # the default bench line as the driver runs it
   ( time timeout -k 10 900 python bench.py > $OUT/r03b_bench.json 2> $OUT/r03b_bench.err ) 2>&1 | tail -3 | tee -a $P; python tools/show_bench.py $OUT/r03b_bench.json | tee -a $P
   ;;
+m)   # mixed precision: tests, then rates (fp32 handle: mixed vs pure; fp64 handle: fp32 start vs plain)
+  timeout -k 10 900 python -m pytest tests -m gpu -q -k "f32 or tile_pool or multi_phase or lds_resident or deferred or config3" > $OUT/r03m_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -8 $OUT/r03m_pytest.log
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03m_$tag.json 2> $OUT/r03m_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03m_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  kernel_ms %.3f" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["roofline"]["kernel_ms_avg"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for i in 2 4; do run head_f64_i$i --steps 60 --inflight $i; done
+  for i in 2 3 4; do run head_f64_f32start_i$i --steps 60 --inflight $i --f64-f32-start; done
+  run head_f64_f32start_mu1e3 --steps 60 --inflight 3 --f64-f32-start --switch-mu 1e-3
+  for i in 2 4; do run head_f32_mixed_i$i --steps 60 --precision f32 --inflight $i; done
+  run head_f32_pure_i4 --steps 60 --precision f32 --f32-pure --inflight 4
+  for i in 4 8; do run w32_mixed_i$i --steps 40 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight $i; done
+  run w32_pure_i4 --steps 40 --weights-sweep --precision f32 --f32-pure --no-traj --batch 131072 --inflight 4
+  run w32_pure_i4_c24 --steps 60 --weights-sweep --precision f32 --f32-pure --no-traj --batch 131072 --inflight 4 --tail-cut 24
+  ;;
 esac
 echo done | tee -a $P
