@@ -316,8 +316,9 @@ def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
 
     def leg(name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered", velocity_weights=(0.0, 1.0, 100.0), note=None,
-            tail_cut=0, steps=None, f32_pure=False):
+            tail_cut=0, steps=None, f32_pure=False, f32_start=False):
         params = pkg.params_from_json(os.path.join(golden, config), **over)
+        params.f64_f32_start = 1 if f32_start else 0
         if f32:
             params.precision = pkg.PRECISION_F32
             params.f32_finish = 0 if f32_pure else 1
@@ -348,6 +349,11 @@ def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
                              note="28 of the 65 536 instances need 100-400 iterations (9 end at the iteration cap, 19-20 with a failed line search, in the "
                                   "oracle as on the device): their serial chains last 70-100 ms.  Deferred tails (tail_cut 20) take them out of the launches; "
                                   "every batch, stragglers included, is final inside the timed region (the drain of the last tails is part of it)")
+    legs["headline_f32_start"] = leg("the headline workload (configs[2]) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above "
+                                     "2e-5) on the fp32 record, every instance finished by the fp64 solver to the same tol and polish; three batches in "
+                                     "flight", "config-fast.json", {}, 65536, "lake", False, False, True, 3, steps=60, f32_start=True,
+                                     note="measured 1.12-1.14x the plain fp64 solve on the same box, below the 1.15x set for making it the default: "
+                                          "opt-in (DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")
     legs["configs_1"] = leg("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json", "config-stable.json", {}, 4096, "straight",
                             False, False, True, 2)
     legs["configs_3_share"] = leg("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",

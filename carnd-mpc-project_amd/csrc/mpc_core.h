@@ -1436,6 +1436,11 @@ struct Solver {
   MPC_HD void promoted() {
     phase = PH_EVAL0; keep_theta = true; ls_start = false; nf = 0; n_polish = 0; out_step = out_prev = IC::huge;
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
+#if MPC_S0_VARIABLE
+    /* psi_0 / v_0 have arrived at their pinned values long before a hand-over (a factor 100 per iteration); the other
+     * precision's copy of them may lie outside THIS solver's relaxed bounds by its rounding, so they are taken as arrived */
+    p0 = st[2]; v0k = st[3];
+#endif
   }
 
   MPC_HD void begin(bool ls) {

@@ -238,8 +238,10 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
 #pragma unroll
               for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
             }
-            const int s0 = S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, !T.resume);
-            if (T.resume) {
+            const bool from_scratch = T.promote_in && T.in_park[pos + 35 * T.ld_park] != 0.0;   /* the fp32 phase gave up on it */
+            const int s0 = S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, !T.resume || from_scratch);
+            if (from_scratch) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
+            else if (T.resume) {
               /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
               const double *pk = T.in_park + pos;
               const int64_t lp = T.ld_park;
@@ -285,14 +287,17 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     if (have) {
       const int r = S.step();
       ++passes;
-      if (r == SV::MPC_PROMOTE) {
-        /* mixed precision: this phase has taken the instance as far as it is asked to; the next phase's solver takes over */
+      if (r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) {
+        /* mixed precision: this phase has taken the instance as far as it is asked to; the next phase's solver takes over.
+         * Not-a-number in the fp32 phase (states far from the origin late in a closed loop: x^4 terms, lost digits) is not a
+         * verdict on the instance: the fp64 solver gets it from the start point (row 35 of the parked scalars says so). */
         const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
         T.out_inst[pos] = (int32_t)i;
         T.out_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
         double *pk = T.out_park + pos;
         const int64_t lp = T.ld_park;
         S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
+        pk[35 * lp] = r == SV::MPC_PROMOTE ? 0.0 : 1.0;
         have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
       } else if (r != SV::MPC_RUNNING) {
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
@@ -363,7 +368,7 @@ struct MpcTailArgs {
   MpcTailSlot slot[kTailPerLaunch];
 };
 
-template <bool STAGING, class R, int OCC>
+template <bool STAGING, class R, int OCC, class RIO = R>
 __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P, const MpcTailArgs A, R *__restrict__ wsbase,
                                                                const int64_t tile_reals) {
   extern __shared__ double smem[];
@@ -392,10 +397,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P
           for (int j = 0; j < A.n_slots; j++)        /* uniform j: the slot's pointers come through the scalar unit */
             if (j == sj) {
               const MpcTailSlot &D = A.slot[j];
-              R *o = (R *)D.out + i;
-              R *t = D.traj ? (R *)D.traj + i : nullptr;
+              RIO *o = (RIO *)D.out + i;
+              RIO *t = D.traj ? (RIO *)D.traj + i : nullptr;
               const int64_t l = D.ldo;
-              S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, t != nullptr, ylo_user, yhi_user);
+              S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, t != nullptr,
+                       ylo_user, yhi_user);
               D.status[i] = fin_status;
               if (D.iters) D.iters[i] = S.iters + it_total;
             }
@@ -691,6 +697,7 @@ struct MpcHandle {
     hipEvent_t bulk = nullptr;   /* recorded behind the batch's own launch */
   };
   bool tail_ready = false;
+  bool tail_double = true;     /* the solver of the tail launches: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
   int tail_ring = 0, tail_waves = 256, tail_priority = 0;
   int64_t tail_cap = 0, tail_min_batch = 4096;
   int n_tail_streams = 2;
@@ -959,10 +966,13 @@ static int launch_lds(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R 
 }
 
 /* ---- deferred tails: queue storage, the tail launch, waiting for a batch ---- */
-static int tail_prepare(MpcHandle *h, size_t real_bytes) {
+static int tail_prepare(MpcHandle *h) {
   if (h->tail_ready) return MPC_OK;
   const MpcParams &P = h->params;
-  const bool f32 = P.precision == MPC_PRECISION_F32;
+  h->tail_double = P.precision != MPC_PRECISION_F32 || h->mixed;      /* a mixed-precision solve defers in its fp64 phase */
+  const bool f32 = !h->tail_double;
+  const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
+  const int64_t tail_stride = f32 ? h->ws_stride_f32 : h->ws_stride_f64;
   h->tail_ring = P.tail_ring < 2 ? 2 : (P.tail_ring > kTailMaxRing ? kTailMaxRing : P.tail_ring);
   int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 8;
   if (cap < 256) cap = 256;
@@ -996,7 +1006,7 @@ static int tail_prepare(MpcHandle *h, size_t real_bytes) {
   MPC_HIP_CHECK(hipMalloc((void **)&h->d_tinst, sizeof(int32_t) * K * cp));
   MPC_HIP_CHECK(hipMalloc((void **)&h->d_tpark, sizeof(double) * K * kTailRows * cp));
   MPC_HIP_CHECK(hipMalloc((void **)&h->d_titer, h->titer_slot_bytes * K));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)h->ws_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
+  MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
   for (int q = 0; q < kTailMaxRing; q++) {
     MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tslot[q].bulk, hipEventDisableTiming));
     MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tail_ev[q], hipEventDisableTiming));
@@ -1021,8 +1031,9 @@ static int tail_flush(MpcHandle *h, int si = -1) {
     for (int q = 0; q < h->n_tail_streams; q++) if (h->stream_launch[q] < h->stream_launch[si]) si = q;
   }
   const int64_t cp = h->tail_cap;
-  const bool f32 = h->params.precision == MPC_PRECISION_F32;
+  const bool f32 = !h->tail_double, io32 = h->params.precision == MPC_PRECISION_F32;
   const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
+  const int64_t tail_stride = f32 ? h->ws_stride_f32 : h->ws_stride_f64;
   for (int first = 0; first < n; first += kTailPerLaunch) {
     const int m = n - first < kTailPerLaunch ? n - first : kTailPerLaunch;
     MpcTailArgs A;
@@ -1044,13 +1055,15 @@ static int tail_flush(MpcHandle *h, int si = -1) {
     MPC_HIP_CHECK(hipMemsetAsync(A.take, 0, sizeof(int32_t), ts));
     int64_t waves = (int64_t)m * (cp / 64);
     if (waves > h->tail_waves) waves = h->tail_waves;
-    void *wsp = (char *)h->tail_ws + (size_t)si * (size_t)h->ws_stride * (size_t)h->tail_waves * real_bytes;
+    void *wsp = (char *)h->tail_ws + (size_t)si * (size_t)tail_stride * (size_t)h->tail_waves * real_bytes;
     if (f32 && h->occ2)
-      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 2>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, h->ws_stride);
+      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 2>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, tail_stride);
     else if (f32)
-      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, h->ws_stride);
+      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, tail_stride);
+    else if (io32)       /* the fp64 phase of a mixed-precision solve: fp32 arrays at the ABI */
+      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1, float>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, tail_stride);
     else
-      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, h->ws_stride);
+      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, tail_stride);
     MPC_HIP_CHECK(hipGetLastError());
     MPC_HIP_CHECK(hipEventRecord(h->tail_ev[L % kTailMaxRing], ts));
     h->stream_launch[si] = L;
@@ -1150,7 +1163,7 @@ extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
 template <class RIO>
 static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const RIO *state, const RIO *coeffs, const RIO *yaw_lo,
                         const RIO *yaw_hi, const RIO *weights, RIO *out, RIO *traj, int32_t *status, int32_t *iters, hipStream_t s,
-                        bool with_stats) {
+                        const MpcPhase &tail) {
   const int64_t tiles = h->io_stride / 64;
   if (!h->ws2) {
     /* h->ws holds the handle's own layout; the phases need one workspace of each */
@@ -1182,12 +1195,13 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.src_ws = ws32; U.src_tile_reals = h->ws_stride_f32;
   U.resume = 1; U.promote_in = 1;
   U.refill_min = h->refill_min; U.refill_wait = h->refill_wait;
+  /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
+  U.tail_cut = tail.tail_cut; U.t_cap = tail.t_cap; U.t_count = tail.t_count; U.t_inst = tail.t_inst; U.t_park = tail.t_park; U.t_iter = tail.t_iter;
   hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
-  if (with_stats) return record_stats(h, B, status, it_out, s);
   return MPC_OK;
 }
 
@@ -1214,13 +1228,12 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  if (h->mixed) return launch_mixed<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s, with_stats);
-  const bool defer = may_defer && h->params.tail_cut > 0 && B >= h->tail_min_batch && !(h->lds_lanes > 0 && B <= h->lds_max_batch);
+  const bool defer = may_defer && h->params.tail_cut > 0 && B >= h->tail_min_batch && (h->mixed || !(h->lds_lanes > 0 && B <= h->lds_max_batch));
   const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
   MpcHandle::TailSlot *ts = nullptr;
   int slot_index = 0;
   if (defer) {
-    const int rc = tail_prepare(h, sizeof(R));
+    const int rc = tail_prepare(h);
     if (rc != MPC_OK) return rc;
     slot_index = (int)(h->n_deferred % h->tail_ring);
     ts = &h->tslot[slot_index];
@@ -1231,6 +1244,34 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
       MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->tail_ev[ts->launch % kTailMaxRing], 0));
     }
     MPC_HIP_CHECK(hipMemsetAsync(h->d_tcount + slot_index, 0, sizeof(int32_t), (hipStream_t)stream_));
+  }
+  auto tail_fields = [&](MpcPhase &T) {
+    T.tail_cut = defer ? h->params.tail_cut : 0; T.t_cap = (int32_t)h->tail_cap;
+    T.t_count = defer ? h->d_tcount + slot_index : nullptr;
+    T.t_inst = defer ? h->d_tinst + (int64_t)slot_index * h->tail_cap : nullptr;
+    T.t_park = defer ? h->d_tpark + (int64_t)slot_index * kTailRows * h->tail_cap : nullptr;
+    T.t_iter = defer ? (void *)((char *)h->d_titer + (size_t)slot_index * h->titer_slot_bytes) : nullptr;
+  };
+  auto tail_done = [&]() -> int {
+    if (!defer) return MPC_OK;
+    ts->batch_id = h->batch_seq; ts->launch = -1;
+    ts->out = out; ts->traj = traj; ts->status = status; ts->iters = iters; ts->ldo = ldo;
+    MPC_HIP_CHECK(hipEventRecord(ts->bulk, s));
+    ++h->n_deferred;
+    /* self-clocked: a tail launch goes out whenever a tail stream has finished its previous one, and serves every batch that
+     * came in meanwhile -- so however long the stragglers take, no launch queues behind another */
+    return tail_clock(h);
+  };
+  if (h->mixed) {
+    MpcPhase TT;
+    memset(&TT, 0, sizeof(TT));
+    tail_fields(TT);
+    const int rc = launch_mixed<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s, TT);
+    if (rc != MPC_OK) return rc;
+    const int rt = tail_done();
+    if (rt != MPC_OK) return rt;
+    if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
+    return MPC_OK;
   }
   if (n_cuts > 0 && !h->ws2) {
     const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(R);
@@ -1282,11 +1323,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
     T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
-    T.tail_cut = defer ? h->params.tail_cut : 0; T.t_cap = (int32_t)h->tail_cap;
-    T.t_count = defer ? h->d_tcount + slot_index : nullptr;
-    T.t_inst = defer ? h->d_tinst + (int64_t)slot_index * h->tail_cap : nullptr;
-    T.t_park = defer ? h->d_tpark + (int64_t)slot_index * kTailRows * h->tail_cap : nullptr;
-    T.t_iter = defer ? (void *)((char *)h->d_titer + (size_t)slot_index * h->titer_slot_bytes) : nullptr;
+    tail_fields(T);
     const bool pooled = h->pool && n_cuts == 0;      /* a parked iterate stays in its column: phases keep their own tiles */
     T.pool_bits = pooled ? h->pool->bits : nullptr; T.pool_base = pooled ? h->pool->base : nullptr;
     T.pool_tiles = pooled ? h->pool->tiles : 0; T.pool_words = pooled ? h->pool->words : 0;
@@ -1296,15 +1333,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
-  if (defer) {
-    ts->batch_id = h->batch_seq; ts->launch = -1;
-    ts->out = out; ts->traj = traj; ts->status = status; ts->iters = iters; ts->ldo = ldo;
-    MPC_HIP_CHECK(hipEventRecord(ts->bulk, s));
-    ++h->n_deferred;
-    /* self-clocked: a tail launch goes out whenever a tail stream has finished its previous one, and serves every batch that
-     * came in meanwhile -- so however long the stragglers take, no launch queues behind another */
-    { const int rf = tail_clock(h); if (rf != MPC_OK) return rf; }
-  }
+  { const int rt = tail_done(); if (rt != MPC_OK) return rt; }
   if (with_stats) return record_stats(h, B, status, it_out, s);
   return MPC_OK;
 }

@@ -213,6 +213,11 @@ extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t 
           in_double = true;
           continue;
         }
+        if (r == MPC_STATUS_NUMERIC && !in_double) {      /* not-a-number in fp32 is not a verdict: fp64 solves it from the start point */
+          (void)D.setup(std_, cfd, (double)yaw_lo[i], (double)yaw_hi[i], wd, true);
+          D.begin(true); attempt = 0; it_total = 0; in_double = true;
+          continue;
+        }
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           attempt = 1;
           if (in_double) { it_total += D.iters; D.start_point(); D.begin(false); }

@@ -104,5 +104,30 @@ PY
   run w32_pure_i4 --steps 40 --weights-sweep --precision f32 --f32-pure --no-traj --batch 131072 --inflight 4
   run w32_pure_i4_c24 --steps 60 --weights-sweep --precision f32 --f32-pure --no-traj --batch 131072 --inflight 4 --tail-cut 24
   ;;
+n)   # mixed precision with deferred tails; switch_mu sweep on the fp64 headline
+  timeout -k 10 900 python -m pytest tests -m gpu -q -k "deferred or f32" > $OUT/r03n_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -8 $OUT/r03n_pytest.log
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03n_$tag.json 2> $OUT/r03n_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03n_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  kernel_ms %.3f" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["roofline"]["kernel_ms_avg"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for c in 8 12 16 24; do run w32_mixed_c$c --steps 80 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 4 --tail-cut $c; done
+  run w32_mixed_c12_i8 --steps 80 --weights-sweep --precision f32 --no-traj --batch 131072 --inflight 8 --tail-cut 12
+  for mu in 2e-6 2e-5 2e-4; do run head_f64_f32start_mu$mu --steps 100 --inflight 3 --f64-f32-start --switch-mu $mu; done
+  run head_f64_plain --steps 100 --inflight 2
+  run head_f64_f32start_i3_b --steps 100 --inflight 3 --f64-f32-start
+  run head_f64_plain_b --steps 100 --inflight 2
+  run head_f64_f32start_c10 --steps 200 --inflight 3 --f64-f32-start --tail-cut 10
+  run survey_f32start_c12 --steps 300 --inflight 3 --f64-f32-start --tail-cut 12 --population survey --tail-ring 64
+  run w64_f32start_c12 --steps 80 --weights-sweep --inflight 4 --f64-f32-start --tail-cut 12
+  run n25_f32start_c12 --steps 60 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4 --f64-f32-start --tail-cut 12
+  ;;
+p)   # parity of the fp64 solve with its early iterations on the fp32 record (MPC_MIXED=1 forces f64_f32_start on every fp64 handle)
+  MPC_MIXED=1 timeout -k 10 900 python -m pytest tests -m gpu -q -k "matches_oracle or scipy or full_size_properties or soak or test_cpp or horizon_extremes or rollout or plot_anchors or run_path" > $OUT/r03p_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -12 $OUT/r03p_pytest.log
+  ;;
 esac
 echo done | tee -a $P
