@@ -567,8 +567,10 @@ def main():
         except Exception:
             continue
         for e in pj.get("entries", [pj]):
+            mixed_now = (f32 and bool(params.f32_finish)) or (not f32 and bool(params.f64_f32_start))
             if (e.get("batch") == B and e.get("config") == args.config and e.get("N", 10) == params.N and e.get("dtype", "f64") == dtype
-                    and bool(e.get("weights_sweep", False)) == bool(args.weights_sweep) and bool(e.get("traj", True)) == want_traj):
+                    and bool(e.get("weights_sweep", False)) == bool(args.weights_sweep) and bool(e.get("traj", True)) == want_traj
+                    and (e.get("mixed_precision", "no") != "no") == mixed_now):
                 traffic = e.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/%s: rocprofv3 PMC passes of this workload on another run (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" % name
                 break

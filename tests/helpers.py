@@ -191,6 +191,23 @@ def garbage_batch(batch, weights):
     return b, w, [d[0] for d in defects]
 
 
+def f32_forks(got, ref, ok):
+    """Instances on which an MPC_PRECISION_F32 solve (fp32 iterations, fp64 finish) and the fp64 reference both converge, to
+    DIFFERENT local minima: beyond the stated tolerances in delta0 / a0 / step-1 state / trajectory while the costs agree to 1e-3
+    relative.  The NLP is non-convex and on a flat objective (velocity weight 0, steering weight 1) the fp32 iterations can lead
+    into a neighbouring basin; measured on configs[4]'s 131 072-instance share: one such instance (the mixed solve found the lower
+    cost) by the first step; with the trajectory in the comparison, on a 65 536-instance soak: three (first steps equal to 1e-4,
+    far ends of the trajectories 0.01-0.67 m apart, costs within 3e-5).  The tests bound them at one in 10 000.
+    Returns (fork mask, wrong mask): `wrong` = beyond tolerance with costs that do NOT agree."""
+    g, r = got["out"].astype(np.float64), ref["out"]
+    far = (np.abs(g[6] - r[6]) > F32_TOL_STEER) | (np.abs(g[7] - r[7]) > F32_TOL_ACCEL) | (np.abs(g[:6] - r[:6]).max(0) > F32_TOL_STATE)
+    if got.get("traj") is not None and ref.get("traj") is not None:
+        far = far | (np.abs(got["traj"].astype(np.float64) - ref["traj"]).max(0) > F32_TOL_TRAJ)
+    far = far & ok
+    same_cost = np.abs(g[8] - r[8]) <= 1e-3 * np.maximum(1.0, np.abs(r[8]))
+    return far & same_cost, far & ~same_cost
+
+
 def closed_loop_report(hist, step_status, ref_hist, ref_status):
     """Closed loops (src/test.cpp:79-111) of two solvers side by side: hist [steps, 9, cars] and the status of every solve
     [steps, cars] of each.  EVERY solve is counted.  A car is "comparable" up to and including its first solve that either

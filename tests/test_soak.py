@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as O
 from helpers import (F32_TOL_ACCEL, F32_TOL_COST_REL, F32_TOL_STATE, F32_TOL_STEER, F32_TOL_TRAJ, TOL_ACCEL, TOL_COST_REL, TOL_STEER,
-                     TOL_TRAJ, closed_loop_report)
+                     TOL_TRAJ, closed_loop_report, f32_forks)
 
 pytestmark = [pytest.mark.gpu]
 
@@ -93,11 +93,14 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
         got = {k: v.cpu().numpy() for k, v in r.items()}
     ref = _oracle_all("config-fast.json", {}, {k: np.ascontiguousarray(b[k], dtype=np.float64) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}, w, workers)
     ok = (got["status"] == 0) & (ref["status"] == 0)
+    fork, wrong = f32_forks(got, ref, ok)                                 # other local minima: counted, bounded, reported
+    ok = ok & ~fork
     d = np.abs(got["out"].astype(np.float64) - ref["out"])[:, ok]
     dt_ = np.abs(got["traj"].astype(np.float64) - ref["traj"])[:, ok].max(0)
     dc = d[8] / np.maximum(1.0, np.abs(ref["out"][8][ok]))
     q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.999, 1.0)]
     row = {"workload": "fp32 weight sweep (configs[4] shape) against the fp64 oracle", "instances": B,
+           "instances_on_another_local_minimum": np.where(fork)[0].tolist(), "instances_wrong": int(wrong.sum()),
            "status_device": np.bincount(got["status"], minlength=5).tolist(), "status_oracle": np.bincount(ref["status"], minlength=5).tolist(),
            "both_converged": int(ok.sum()), "mean_iterations_device": float(got["iters"].mean()), "mean_iterations_oracle": float(ref["iters"].mean()),
            "quantiles": "p50, p99, p99.9, max", "d_steer_rad": q(d[6]), "d_accel": q(d[7]), "d_step1_state": q(d[:6].max(0)), "d_trajectory_m": q(dt_), "d_cost_rel": q(dc)}
@@ -105,6 +108,7 @@ def test_soak_f32_weight_sweep_against_the_oracle(pkg, golden_dir, waypoints):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(row, open("gpurun_out/soak_f32.json", "w"), indent=1)
     assert np.array_equal(got["status"], ref["status"]), row             # an instance ends with the status the fp64 oracle gives it
+    assert wrong.sum() == 0 and fork.sum() <= max(2, B // 10000), row
     assert d[6].max() <= F32_TOL_STEER and d[7].max() <= F32_TOL_ACCEL and d[:6].max() <= F32_TOL_STATE and dt_.max() <= F32_TOL_TRAJ and dc.max() <= F32_TOL_COST_REL, row
 
 

@@ -22,23 +22,44 @@ json.dump(bench, open(os.path.join(P, name + "_bench.json"), "w"), indent=1)
 GRID = (bench["config"]["batch_per_gpu"] + 63) // 64 * 64
 
 
+def short(kname):
+    """mpc_solve_kernel<true, double, 1, double, float> -> 'solve<double,1,double,float>' (solver reals, waves/SIMD, ABI reals, source reals)"""
+    i = kname.find("<")
+    args = kname[i + 1:kname.rfind(">")].replace(" ", "").split(",") if i >= 0 else []
+    base = "tail" if "mpc_tail" in kname else "solve"
+    return base + "<" + ",".join(args[1:]) + ">"
+
+
 def pmc(sub, kernel):
     rows = list(csv.DictReader(open(os.path.join(G, tag + "_" + sub, "pmc_counter_collection.csv"))))
     agg = collections.defaultdict(list)
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for r in rows:
         # only the launches of the benchmarked batch (the bench also makes small launches, e.g. its B = 1 latency leg)
         if kernel in r["Kernel_Name"] and int(r["Grid_Size"]) == GRID:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
-    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}, meta
+    phases = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items()}
+    if len(phases) > 1:       # a mixed-precision solve is two launches per batch: per batch = the sum over its phases
+        tot = collections.defaultdict(float)
+        for d in phases.values():
+            for c, v in d.items():
+                tot[c] += v
+        return dict(tot), {k: len(v) for k, v in agg.items()}, meta, phases
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}, meta, phases
 
 
 out = {"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (separate passes)",
        "kernel": "mpc_solve_kernel", "per": "launch (mean over the profiled launches)"}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    m, n, meta = pmc(sub, "mpc_solve_kernel")
+    m, n, meta, phases = pmc(sub, "mpc_solve_kernel")
     out.update(m); out.setdefault("launches", {}).update(n)
+    if len(phases) > 1:
+        out["per"] = "batch = the sum over the phases of a mixed-precision solve (each phase: mean over its profiled launches)"
+        for k, d in phases.items():
+            out.setdefault("phases", {}).setdefault(k, {}).update(d)
     # rocprofv3's per-dispatch fields, as reported: VGPR_Count is the arch-VGPR allocation granule-rounded and Accum/LDS are
     # not filled in for this kernel on ROCm 7.2 -- the kernel's real footprint is in tools/isa_report.py (ISA metadata)
     out["dispatch_fields_as_reported_by_rocprofv3"] = meta
@@ -64,8 +85,9 @@ json.dump(out, open(os.path.join(P, name + "_pmc_summary.json"), "w"), indent=1)
 cfg = bench["config"]
 entry = {"batch": cfg["batch_per_gpu"], "config": "config-fast.json" if "config-fast" in cfg["workload"] else "config-stable.json", "N": cfg["N"],
          "dtype": bench["dtype"], "weights_sweep": "weight sweep" in cfg["workload"], "traj": "trajectories on" in cfg["workload"],
-         "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "from": name + "_pmc_summary.json"}
-tf = os.path.join(P, "r02_pmc_traffic.json")
+         "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "from": name + "_pmc_summary.json",
+         "mixed_precision": cfg.get("mixed_precision", "no")}
+tf = os.path.join(P, name.split("_")[0] + "_pmc_traffic.json")
 allt = json.load(open(tf)) if os.path.exists(tf) else {"entries": []}
 allt["entries"] = [e for e in allt["entries"] if e["from"] != entry["from"]] + [entry]
 json.dump(allt, open(tf, "w"), indent=1)
