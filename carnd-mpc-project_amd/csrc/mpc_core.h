@@ -75,7 +75,8 @@ namespace mpc {
  * In the fp64 solver everything is fp64: storing the direction or the gains in fp32 was tried and rejected -- an
  * absolute error of ~1e-8 in a step component is fatal next to slacks of ~1e-9 at active bounds
  * (+11 % iterations and a few non-converged instances on the 65 536-instance workload).  The fp32 solver
- * (MPC_PRECISION_F32) runs to a tolerance of 1e-4 with a barrier floor of 1e-5, where fp32 steps are adequate. */
+ * runs to tol_f32 = 5e-4 with a barrier floor of tol_f32 / 25 = 2e-5, where fp32 steps are adequate; as the first phase of
+ * a mixed-precision solve it hands over to the fp64 solver before that (MPC_PROMOTE). */
 template <class R> struct Layout;
 template <> struct Layout<double> { enum : int { G = 2, F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 14, F_ZU = 18, IT_SZ = 22 }; };
 template <> struct Layout<float> { enum : int { G = 4, F_S = 0, F_U = 6, F_LAM = 8, F_ZL = 16, F_ZU = 20, IT_SZ = 24 }; };
