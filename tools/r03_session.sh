@@ -136,5 +136,15 @@ g)   # profiles: the default headline, then the same with its early iterations o
 s)   # the soak tests at full size (every instance against the oracle on the box's cores)
   MPC_SOAK=1 timeout -k 10 1100 python -m pytest tests/test_soak.py -m gpu -q -s > $OUT/r03s_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r03s_pytest.log
   ;;
+c)   # collective rehearsal on one GPU: RCCL initialised with a single rank, the per-batch collective inside the timed region
+  for g in root all; do for extra in "" "--gather-results-only"; do
+    timeout -k 10 300 python bench.py --force-collective --gather $g $extra --steps 40 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_${g}${extra:+_ro}.json 2> $OUT/r03c_${g}${extra:+_ro}.err; echo "$g $extra exit=$?" | tee -a $P
+    python -c "import json; r=json.load(open('$OUT/r03c_${g}${extra:+_ro}.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], 'bytes/rank/batch', r['config']['gather_bytes_sent_per_rank_per_batch'])" | tee -a $P
+  done; done
+  timeout -k 10 300 python bench.py --force-collective --population survey --tail-cut 20 --tail-ring 64 --steps 200 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_tails.json 2> $OUT/r03c_tails.err; echo "tails exit=$?" | tee -a $P
+  python -c "import json; r=json.load(open('$OUT/r03c_tails.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], r['status_counts'])" | tee -a $P
+  timeout -k 10 300 python bench.py --gpus 2 --single-device --backend gloo --steps 20 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_gloo2.json 2> $OUT/r03c_gloo2.err; echo "gloo2 exit=$?" | tee -a $P
+  python -c "import json; r=json.load(open('$OUT/r03c_gloo2.json')); print('  ', r['value']/1e6, 'M solves/s', r['n_gpus'], r['config']['collective_mode'], 'checked', r['config']['gather_checked'])" | tee -a $P
+  ;;
 esac
 echo done | tee -a $P
