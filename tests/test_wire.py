@@ -139,3 +139,44 @@ def test_replay_tool_over_tcp(pkg, golden_dir, waypoints):
         if p.poll() is None:
             p.kill()
     assert got.decode() == ref.stdout and got.count(b"\n") == 2 * B
+
+
+@pytest.mark.gpu
+def test_host_telemetry_entry_runs_on_the_handles_device_and_reports_errors(pkg, golden_dir, waypoints):
+    """mpc_telemetry_batch_host / mpc_wire_telemetry_batch_host: host arrays in and out on the HANDLE's device and stream
+    (mpc_handle_device says which), the same numbers as the device entry point; unknown options of the replay tool and
+    mixed waypoint counts are refused with a message."""
+    import ctypes as C
+    import torch
+    cfgname = "config-fast.json"
+    params = pkg.params_from_json(os.path.join(golden_dir, cfgname))
+    B = 40
+    _, rows, tel = _frames_for(pkg, params, waypoints, B, 74)
+    lib = pkg.library()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    tel6, px, py = c(rows), c(tel["ptsx"]), c(tel["ptsy"])
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        assert lib.mpc_handle_device(mpc._h) == 0
+        cmd = np.zeros((2, B)); status = np.zeros(B, dtype=np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        assert lib.mpc_telemetry_batch_host(mpc._h, B, B, 6, p(tel6), 0.0, p(px), p(py), p(cmd), p(status)) == 0
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(a.copy()).to(dev)
+        d_cmd = torch.zeros((2, B), dtype=torch.float64, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_px, d_py, d_tel = t(px), t(py), t(tel6)
+        assert lib.mpc_telemetry_batch_device(mpc._h, B, B, 6, C.c_void_p(d_tel.data_ptr()), 0.0, C.c_void_p(d_px.data_ptr()), C.c_void_p(d_py.data_ptr()),
+                                              C.c_void_p(d_cmd.data_ptr()), None, C.c_void_p(d_st.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d_cmd.cpu().numpy(), cmd) and np.array_equal(d_st.cpu().numpy(), status)
+        assert np.array_equal(px, c(tel["ptsx"]))                                   # the host entry leaves the caller's waypoints alone
+        # frames with different waypoint counts in one batch are refused, with a message
+        W = pkg.MpcWireTelemetry * 2
+        w = W()
+        w[0].npts, w[1].npts = 6, 5
+        rc = lib.mpc_wire_telemetry_batch_host(mpc._h, 2, w, None, 0.0, p(cmd), p(status))
+        assert rc == -1 and b"same number of waypoints" in lib.mpc_last_error()
+    exe = os.path.join(os.path.dirname(pkg.library_path()), "mpc_replay")
+    r = subprocess.run([exe, os.path.join(golden_dir, cfgname), "--cars"], input="", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown or incomplete option" in r.stderr
+    r = subprocess.run([exe, os.path.join(golden_dir, cfgname), "--bogus", "1"], input="", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
