@@ -116,6 +116,11 @@ struct Config {
   /* solver controls that have no counterpart among the reference's statics */
   inline static int maxIterations = 200;
   inline static double tolerance = 1e-8;
+  /* One MPC::solve() per telemetry message is a single serial chain on the device, and a lone wave issues fp32 work four
+   * times as fast as fp64: with the early iterations on the fp32 record (MpcParams.f64_f32_start; every solve still finished
+   * by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes 0.54 ms instead of 0.70 ms.  Same answers at the
+   * stated 1e-6; not bitwise those of the single-phase solve.  0 = single phase. */
+  inline static int fp32Start = 1;
 
   /* Config::load(fileName), Config.cpp:31-87 (parsing and unit conversion live behind the C ABI) */
   static void load(const std::string &fileName) {
@@ -140,6 +145,7 @@ struct Config {
     p.max_acceleration = maxAcceleration; p.max_deceleration = maxDeceleration; p.max_speed = maxSpeed;
     p.steer_adj_thresh = steerAdjustmentThresh; p.steer_adj_ratio = steerAdjustmentRatio; p.Lf = Lf;
     p.cte_panic = ctePanic; p.epsi_panic = epsiPanic; p.max_iter = maxIterations; p.tol = tolerance;
+    p.f64_f32_start = fp32Start ? 1 : 0;
     for (int i = 0; i < MPC_NW; i++) p.weights[i] = i < (int)weights.size() ? weights[i] : 0.0;
     auto put = [](const std::vector<double> &v, double *dst, int32_t &n) {
       n = (int32_t)(v.size() < MPC_MAX_TABLE ? v.size() : MPC_MAX_TABLE);
@@ -251,15 +257,15 @@ class RoadGeometry {                                                   /* RoadGe
 class MPC {                                                            /* MPC.h:12-56 */
   MpcHandle *handle = nullptr;
   int64_t capacity = 0;
-  int handleN = 0;
+  int handleN = 0, handleFp32Start = 0;
   Vehicle vehicle;
   RoadGeometry roadGeometry;
 
   void ensure(int64_t B) {
     const MpcParams p = Config::snapshot();
-    if (handle && (B > capacity || p.N != handleN)) { mpc_destroy(handle); handle = nullptr; }
+    if (handle && (B > capacity || p.N != handleN || p.f64_f32_start != handleFp32Start)) { mpc_destroy(handle); handle = nullptr; }
     if (!handle) {
-      capacity = B < 1 ? 1 : B; handleN = p.N;
+      capacity = B < 1 ? 1 : B; handleN = p.N; handleFp32Start = p.f64_f32_start;
       int rc = mpc_create(&p, -1, capacity, &handle);
       if (rc != MPC_OK) { handle = nullptr; throw std::string("mpc_create failed: ") + mpc_last_error(); }
     } else if (mpc_set_params(handle, &p) != MPC_OK) throw std::string("mpc_set_params failed: ") + mpc_last_error();
