@@ -355,9 +355,13 @@ def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
                                      note="measured 1.12-1.14x the plain fp64 solve on the same box, below the 1.15x set for making it the default: "
                                           "opt-in (DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")
     legs["configs_1"] = leg("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json", "config-stable.json", {}, 4096, "straight",
-                            False, False, True, 2)
+                            False, False, True, 8, steps=200,
+                            note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")
     legs["configs_3_share"] = leg("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",
                                   "config-stable.json", dict(N=25, dt=0.05), 32768, "lake", False, False, True, 4, tail_cut=24, steps=40)
+    legs["configs_3_share_f32_start"] = leg("the same share with MpcParams.f64_f32_start = 1 (early iterations on the fp32 record: the long-horizon workspace, "
+                                            "640 KB per wave, does not fit the Infinity Cache), eight batches in flight", "config-stable.json", dict(N=25, dt=0.05),
+                                            32768, "lake", False, False, True, 8, steps=40, f32_start=True)
     legs["configs_4_share"] = leg("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, "
                                   "per-instance weight sweep (epsi / v incl. 0 / delta / a)", "config-fast.json", {}, 131072, "lake", True, True, False,
                                   4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance "

@@ -146,5 +146,49 @@ c)   # collective rehearsal on one GPU: RCCL initialised with a single rank, the
   timeout -k 10 300 python bench.py --gpus 2 --single-device --backend gloo --steps 20 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_gloo2.json 2> $OUT/r03c_gloo2.err; echo "gloo2 exit=$?" | tee -a $P
   python -c "import json; r=json.load(open('$OUT/r03c_gloo2.json')); print('  ', r['value']/1e6, 'M solves/s', r['n_gpus'], r['config']['collective_mode'], 'checked', r['config']['gather_checked'])" | tee -a $P
   ;;
+q)   # the long-horizon share and the fp64 weight sweep: plain / fp32 start, with and without deferred tails
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03q_$tag.json 2> $OUT/r03q_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03q_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --steps 60"
+  run n25_plain_i4 $N25 --inflight 4
+  run n25_plain_i4_c24 $N25 --inflight 4 --tail-cut 24 --tail-ring 64
+  run n25_f32s_i4 $N25 --inflight 4 --f64-f32-start
+  run n25_f32s_i6 $N25 --inflight 6 --f64-f32-start
+  run n25_f32s_i4_c16 $N25 --inflight 4 --f64-f32-start --tail-cut 16 --tail-ring 64
+  run n25_f32s_i6_c24 $N25 --inflight 6 --f64-f32-start --tail-cut 24 --tail-ring 64
+  W="--weights-sweep --steps 80"
+  run w64_plain_i4_c24 $W --inflight 4 --tail-cut 24 --tail-ring 64
+  run w64_f32s_i4 $W --inflight 4 --f64-f32-start
+  run w64_f32s_i6_c16 $W --inflight 6 --f64-f32-start --tail-cut 16 --tail-ring 64
+  run w64_f32s_i6_c24 $W --inflight 6 --f64-f32-start --tail-cut 24 --tail-ring 64
+  run c1_plain --config config-stable.json --batch 4096 --steps 200 --inflight 2
+  run c1_f32s --config config-stable.json --batch 4096 --steps 200 --inflight 3 --f64-f32-start
+  run c1_plain_i4 --config config-stable.json --batch 4096 --steps 200 --inflight 4
+  ;;
+r)   # small batches want many in flight; the long-horizon share with more in flight
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03r_$tag.json 2> $OUT/r03r_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03r_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  C1="--config config-stable.json --batch 4096 --steps 400"
+  for i in 6 8 12 16; do run c1_plain_i$i $C1 --inflight $i; done
+  for i in 8 16; do run c1_f32s_i$i $C1 --inflight $i --f64-f32-start; done
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --steps 60"
+  run n25_f32s_i8 $N25 --inflight 8 --f64-f32-start
+  run n25_plain_i8 $N25 --inflight 8
+  run n25_plain_i8_c24 $N25 --inflight 8 --tail-cut 24 --tail-ring 64
+  ;;
 esac
 echo done | tee -a $P
