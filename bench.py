@@ -97,6 +97,8 @@ def parse_args(argv=None):
                          "'unfiltered' keeps every draw with a finite fit")
     ap.add_argument("--gather", choices=("root", "all"), default="root", help="the batch's one collective: gather to rank 0 (default; what "
                     "north_star asks for) or all_gather_into_tensor to every rank")
+    ap.add_argument("--gather-group", type=int, default=0, help="batches per collective (default 4 with more than one rank: a collective costs "
+                    "the solve 8-10 %% by being there, whatever it carries; every batch is still gathered inside the timed region)")
     ap.add_argument("--gather-results-only", action="store_true", help="trajectories are computed but stay on their rank: only out[9], status, "
                     "iters travel")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gather synchronously on the solve stream")
@@ -111,6 +113,8 @@ def parse_args(argv=None):
         args.inflight = 4 if args.precision == "f32" else 2
     if args.unfiltered:
         args.population = "unfiltered"
+    if args.gather_group <= 0:
+        args.gather_group = 4 if (args.gpus > 1 or args.force_collective or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 1
     if args.tail_cut < 0:
         args.tail_cut = 0 if args.stub else DEFAULT_TAIL_CUT
     return args
@@ -214,10 +218,12 @@ class Pipeline:
         self.mpcs = [make() for _ in range(self.nfl)]
         self.ring = int(tail_ring) if self.tail else 0
         # buffer sets: one per batch that may be outstanding (in flight, or waiting for its tail and its gather)
-        n_slots = max(2, self.nfl) if not self.tail else self.nfl * (self.ring + 1)
+        g = max(1, int(getattr(args, "gather_group", 1) or 1)) if dist is not None else 1
+        n_slots = max(2, self.nfl, 2 * g) if not self.tail else max(self.nfl * (self.ring + 1), 2 * g)
         tdt = torch.float32 if p.precision == pkg.PRECISION_F32 else torch.float64
         self.pg = pkg.sharding.PackedGather(B, p.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
-                                            slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather == "root", gather_traj=not args.gather_results_only)
+                                            slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather == "root", gather_traj=not args.gather_results_only,
+                                            batches_per_collective=g)
         self.streams, self.gstream = None, None
         if stub is None:
             torch.cuda.synchronize(dev)
@@ -226,7 +232,7 @@ class Pipeline:
             self.streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(self.nfl)]
             self.gstream = torch.cuda.Stream(device=dev)
         self.nstep = 0
-        self.owner = [None] * n_slots           # (handle, batch id) whose results sit in the slot
+        self.owner = [None] * self.pg.slots     # (handle, batch id) whose results sit in the slot
         self.waiting = []                       # batches issued, not yet handed to the gather: (slot, handle, batch id)
         self.lag = self.nfl * max(1, self.ring - 2)
 
@@ -530,8 +536,8 @@ def main():
                                   "on" if want_traj else "off", ", per-instance weight sweep" if args.weights_sweep else "",
                                   ", MPC_PRECISION_F32" if f32 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "N": params.N, "dt": params.dt,
-                   "parallelism": "%d independent shard(s), one %s of the packed results per batch" % (world, pg.collective_name),
-                   "collective_mode": pg.mode, "gather_checked": gather_ok, "gather_bytes_sent_per_rank_per_batch": pg.bytes_sent_per_rank if pg.active else 0,
+                   "parallelism": "%d independent shard(s), one %s of the packed results per %s" % (world, pg.collective_name, "batch" if pg.g == 1 else "%d batches" % pg.g),
+                   "collective_mode": pg.mode, "gather_checked": gather_ok, "gather_bytes_sent_per_rank_per_batch": pg.bytes_sent_per_rank if pg.active else 0, "batches_per_collective": pg.g if pg.active else None,
                    "batches_in_flight": nfl,
                    "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,

@@ -75,45 +75,59 @@ def gather_results(local, B, dist=None, group=None):
 class PackedGather:
     """Zero-copy gather for equal shards (the weak-scaling bench, and any batch divisible by the world size).
 
-    The solver writes its results straight into one packed buffer per rank,
-        rows 0..8 out | status and iters as 2 x int32 per instance (one float64 row, two float32 rows) | 2N trajectory rows (optional),
-    of which the first `gather_rows` rows -- everything, or without the trajectories (gather_traj=False: results only) --
-    are collected with ONE collective per batch: no packing kernels, no re-layout.
-      root_only=False   all_gather_into_tensor: every rank ends up with full[rank, row, instance]
+    The solver writes its results straight into packed buffers per rank,
+        results [slot][9 out rows | status and iters as 2 x int32 per instance (one float64 row, two float32 rows)][instance]
+        trajectories [slot][2N][instance]   (optional)
+    which are collected with ONE collective per `group` consecutive batches (two when the trajectories travel too): no
+    packing kernels, no re-layout.
+      root_only=False   all_gather_into_tensor: every rank ends up with the results of every rank
       root_only=True    gather to rank 0 (what BASELINE.json's north_star asks for: "RCCL only for a final gather"): the other
                         ranks only send -- 1/ws of the inbound bytes per rank, and nothing is written on them
-    `slots` buffer sets alternate, and with overlap=True the collective is issued asynchronously: the gather of batch i
-    runs while batch i+1 is being solved, and a slot is reused only after its gather has completed.
+      gather_traj=False results only: the trajectories stay on their rank
+      group=g           a collective costs the solve 8-10 % by being there, whatever it carries (one-rank rehearsal,
+                        DESIGN.md section 7): g batches share one.  A batch's results are then available when its group's
+                        collective has finished (finish() flushes a partial group).
+    `slots` buffer sets alternate (slots must be a multiple of group), and with overlap=True the collective is issued
+    asynchronously: it runs while the next batches are being solved, and a slot is reused only after its collective has
+    completed.
     """
 
     def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2, dtype=None, force=False,
-                 root_only=False, gather_traj=True):
+                 root_only=False, gather_traj=True, batches_per_collective=1):
         import torch
         if dist is None:
             import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         # force=True runs the collective even with a single rank (rehearsal of the RCCL path on a one-GPU box)
         self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        import os as _os
+        if _os.environ.get("MPC_BENCH_NO_COLLECTIVE_CALLS"):      # measurement aid: the communicator exists, nothing is ever issued
+            self.active = False
         self.ws = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.b, self.N, self.want_traj = int(b), int(N), bool(want_traj)
         self.dtype = dtype if dtype is not None else torch.float64      # float32 for an MPC_PRECISION_F32 handle
         # status and iters are 2 x int32 per instance: one row of float64, two rows of float32
         self.int_rows = 1 if self.dtype == torch.float64 else 2
-        self.rows = 9 + self.int_rows + (2 * self.N if want_traj else 0)
+        self.res_rows = 9 + self.int_rows
         self.gather_traj = bool(gather_traj) and self.want_traj
-        self.gather_rows = 9 + self.int_rows + (2 * self.N if self.gather_traj else 0)
         self.root_only = bool(root_only)
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self.overlap = bool(overlap) and self.nccl
-        self.slots = int(slots)
-        self.pack = [torch.zeros((self.rows, self.b), dtype=self.dtype, device=device) for _ in range(self.slots)]
+        self.g = max(1, int(batches_per_collective))
+        self.slots = (int(slots) + self.g - 1) // self.g * self.g
+        self.is_cuda = torch.device(device).type == "cuda"
+        self.res = torch.zeros((self.slots, self.res_rows, self.b), dtype=self.dtype, device=device)
+        self.trj = torch.zeros((self.slots, 2 * self.N, self.b), dtype=self.dtype, device=device) if self.want_traj else None
         holds_full = self.active and (not self.root_only or self.rank == 0)
-        self.full = [torch.zeros((self.ws, self.gather_rows, self.b), dtype=self.dtype, device=device) if holds_full else None
-                     for _ in range(self.slots)]
-        self.work = [None] * self.slots
+        # gathered copies: [rank][slot][row][instance]
+        self.full_res = torch.zeros((self.ws, self.slots, self.res_rows, self.b), dtype=self.dtype, device=device) if holds_full else None
+        self.full_trj = torch.zeros((self.ws, self.slots, 2 * self.N, self.b), dtype=self.dtype, device=device) if holds_full and self.gather_traj else None
+        self.work = [None] * (self.slots // self.g)         # per group: list of outstanding collectives
+        self.ready = [None] * self.slots                    # per slot: event recorded behind the solve that filled it
+        self.filled = [0] * (self.slots // self.g)          # per group: slots handed to start() since the last collective
         self.collective_name = "gather to rank 0" if self.root_only else "all_gather_into_tensor"
-        self.bytes_sent_per_rank = self.gather_rows * self.b * (8 if self.dtype == torch.float64 else 4)
+        self.bytes_sent_per_rank = (self.res_rows + (2 * self.N if self.gather_traj else 0)) * self.b * (8 if self.dtype == torch.float64 else 4)
         # which collective the timed region really ran: reported in bench.py's JSON line (never a silent fallback)
         if not self.active:
             self.mode = "none (single rank)"
@@ -123,60 +137,98 @@ class PackedGather:
             self.mode = "%s %s through host memory, synchronous (rehearsal backend)" % (dist.get_backend(group), self.collective_name)
         if self.active and not self.gather_traj and self.want_traj:
             self.mode += ", results only (trajectories stay on their rank)"
+        if self.active and self.g > 1:
+            self.mode += ", one collective per %d batches" % self.g
 
     def outputs(self, slot):
-        """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffer of `slot`."""
-        p = self.pack[slot]
+        """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffers of `slot`."""
+        p = self.res[slot]
         ints = p[9:9 + self.int_rows].reshape(-1).view(self.torch.int32)   # 2*b int32
-        return {"out": p[0:9], "traj": p[9 + self.int_rows:9 + self.int_rows + 2 * self.N] if self.want_traj else None,
-                "status": ints[:self.b], "iters": ints[self.b:2 * self.b]}
+        return {"out": p[0:9], "traj": self.trj[slot] if self.want_traj else None, "status": ints[:self.b], "iters": ints[self.b:2 * self.b]}
 
     def wait(self, slot):
-        """Make the current stream wait for the gather that last used `slot` (before the slot is written again)."""
-        w = self.work[slot]
-        if w is not None:
-            w.wait()
-            self.work[slot] = None
+        """Make the current stream wait for the collective that last carried `slot` (before the slot is written again)."""
+        gi = slot // self.g
+        if self.work[gi]:
+            for w in self.work[gi]:
+                w.wait()
+            self.work[gi] = None
 
-    def _collective(self, slot, async_op):
-        dist, src = self.dist, self.pack[slot][:self.gather_rows]
+    def _one(self, full, src, lo, hi, async_op):
+        dist = self.dist
+        part = src[lo:hi]                                     # [g, rows, b], contiguous
         if self.root_only:
-            lst = [self.full[slot][r] for r in range(self.ws)] if self.rank == 0 else None
-            return dist.gather(src, gather_list=lst, dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+            lst = [full[r, lo:hi] for r in range(self.ws)] if self.rank == 0 else None
+            return dist.gather(part, gather_list=lst, dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                group=self.group, async_op=async_op)
-        return dist.all_gather_into_tensor(self.full[slot], src, group=self.group, async_op=async_op)
+        if self.g == self.slots:
+            return dist.all_gather_into_tensor(full, part, group=self.group, async_op=async_op)
+        return dist.all_gather([full[r, lo:hi] for r in range(self.ws)], part, group=self.group, async_op=async_op)
 
-    def start(self, slot):
-        """Gather the packed buffer of `slot` (call after the solve that filled it has been enqueued)."""
-        if not self.active:
-            return
+    def _collect(self, gi, async_op):
+        lo, hi = gi * self.g, (gi + 1) * self.g
+        ws = [self._one(self.full_res, self.res, lo, hi, async_op)]
+        if self.gather_traj:
+            ws.append(self._one(self.full_trj, self.trj, lo, hi, async_op))
+        return ws
+
+    def _issue(self, gi):
         dist, torch = self.dist, self.torch
+        lo, hi = gi * self.g, (gi + 1) * self.g
+        self.filled[gi] = 0
         if self.nccl:
+            if self.is_cuda:                                   # the members of the group were solved on other streams
+                cur = torch.cuda.current_stream()
+                for s in range(lo, hi):
+                    if self.ready[s] is not None:
+                        cur.wait_event(self.ready[s])
             try:
-                w = self._collective(slot, self.overlap)
+                ws = self._collect(gi, self.overlap)
             except RuntimeError as e:
                 if not self.overlap:
                     raise
                 self.overlap = False                      # fall back to the synchronous collective -- and say so
                 self.mode = "rccl %s, synchronous (async_op failed: %s)" % (self.collective_name, str(e).splitlines()[0][:80])
-                w = self._collective(slot, False)
-            self.work[slot] = w if self.overlap else None
+                ws = self._collect(gi, False)
+            self.work[gi] = ws if self.overlap else None
         else:   # gloo (CPU tests, single-GPU rehearsal): through host memory, synchronous
-            src = self.pack[slot][:self.gather_rows]
-            h = (src.cpu() if src.is_cuda else src).contiguous()
-            if self.root_only:
-                parts = [torch.empty_like(h) for _ in range(self.ws)] if self.rank == 0 else None
-                dist.gather(h, gather_list=parts, dst=0, group=self.group)
-                if self.rank == 0:
-                    self.full[slot].copy_(torch.stack(parts, dim=0))
-            else:
-                parts = [torch.empty_like(h) for _ in range(self.ws)]
-                dist.all_gather(parts, h, group=self.group)
-                self.full[slot].copy_(torch.stack(parts, dim=0))
+            for full, src in ((self.full_res, self.res), (self.full_trj, self.trj) if self.gather_traj else (None, None)):
+                if src is None:
+                    continue
+                part = src[lo:hi]
+                h = (part.cpu() if part.is_cuda else part).contiguous()
+                if self.root_only:
+                    parts = [torch.empty_like(h) for _ in range(self.ws)] if self.rank == 0 else None
+                    dist.gather(h, gather_list=parts, dst=0, group=self.group)
+                    if self.rank == 0:
+                        full[:, lo:hi].copy_(torch.stack(parts, dim=0))
+                else:
+                    parts = [torch.empty_like(h) for _ in range(self.ws)]
+                    dist.all_gather(parts, h, group=self.group)
+                    full[:, lo:hi].copy_(torch.stack(parts, dim=0))
+
+    def start(self, slot):
+        """Hand the packed buffers of `slot` to the gather (call on the stream the solve that filled them was enqueued on, after
+        it).  The collective goes out when the last slot of the group has been handed over."""
+        if not self.active:
+            return
+        if self.nccl and self.is_cuda:
+            ev = self.torch.cuda.Event()
+            ev.record()
+            self.ready[slot] = ev
+        gi = slot // self.g
+        self.filled[gi] += 1
+        if self.filled[gi] >= self.g:
+            self._issue(gi)
 
     def finish(self):
-        for s in range(self.slots):
-            self.wait(s)
+        """Flush partial groups and wait for every collective."""
+        if self.active:
+            for gi in range(len(self.filled)):
+                if self.filled[gi] > 0:
+                    self._issue(gi)      # (slots of the group not filled this round carry what they held before)
+        for gi in range(len(self.work)):
+            self.wait(gi * self.g)
 
     def result(self, slot):
         """Views of the gathered batch: out [ws,9,b], traj [ws,2N,b] or None, status/iters [ws,b] (int32); None on a rank
@@ -184,9 +236,8 @@ class PackedGather:
         if not self.active:
             o = self.outputs(slot)
             return {k: (v[None] if v is not None else None) for k, v in o.items()}
-        f = self.full[slot]
-        if f is None:
+        if self.full_res is None:
             return None
+        f = self.full_res[:, slot]
         ints = f[:, 9:9 + self.int_rows].contiguous().reshape(self.ws, -1).view(self.torch.int32).reshape(self.ws, 2 * self.b)
-        return {"out": f[:, 0:9], "traj": f[:, 9 + self.int_rows:9 + self.int_rows + 2 * self.N] if self.gather_traj else None,
-                "status": ints[:, :self.b], "iters": ints[:, self.b:]}
+        return {"out": f[:, 0:9], "traj": self.full_trj[:, slot] if self.gather_traj else None, "status": ints[:, :self.b], "iters": ints[:, self.b:]}

@@ -28,11 +28,11 @@ def test_bench_spawns_its_own_ranks_weak_scaling():
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
     assert r["config"]["global_batch"] == 192 and r["config"]["batch_per_gpu"] == 96
     assert r["config"]["gather_checked"] is True and "gloo" in r["config"]["collective_mode"]
-    assert "gather to rank 0" in r["config"]["collective_mode"]                  # the default: what north_star asks for
+    assert "gather to rank 0" in r["config"]["collective_mode"] and r["config"]["batches_per_collective"] == 4     # the defaults
     assert r["config"]["gather_bytes_sent_per_rank_per_batch"] == 8 * 96 * (9 + 1 + 20)
     assert r["converged_fraction"] == 1.0 and r["value"] > 0 and "stub" in r and r["metric"].startswith("STUB")
     r, _ = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "96", "--stub", "host_twin", "--backend", "gloo", "--gather", "all",
-                 "--gather-results-only"])
+                 "--gather-results-only", "--gather-group", "1"])
     assert "all_gather" in r["config"]["collective_mode"] and "results only" in r["config"]["collective_mode"] and r["config"]["gather_checked"] is True
     assert r["config"]["gather_bytes_sent_per_rank_per_batch"] == 8 * 96 * 10
 

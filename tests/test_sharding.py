@@ -64,7 +64,7 @@ def test_two_rank_shard_solve_gather(host_twin, B):
     assert cut == (0, (B + 1) // 2)
 
 
-def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True):
+def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True, per=1):
     """PackedGather (the bench's zero-copy gather) on CPU tensors over gloo: two alternating buffer sets; all-gather or
     gather to rank 0, with or without the trajectories in the payload."""
     sys.path.insert(0, ROOT)
@@ -73,7 +73,7 @@ def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = 10
-    pg = pkg.sharding.PackedGather(b, N, True, torch.device("cpu"), root_only=root_only, gather_traj=gather_traj)
+    pg = pkg.sharding.PackedGather(b, N, True, torch.device("cpu"), root_only=root_only, gather_traj=gather_traj, batches_per_collective=per)
     ok = pg.active and pg.ws == world and not pg.overlap          # overlap needs RCCL
     ok = ok and pg.bytes_sent_per_rank == 8 * b * (10 + (2 * N if gather_traj else 0))
     for step in range(3):
@@ -89,7 +89,7 @@ def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True):
     pg.finish()
     r = pg.result(2 & 1)
     if root_only and rank != 0:                                    # a rank that only sends holds no gathered copy
-        ok = ok and r is None and pg.full[0] is None
+        ok = ok and r is None and pg.full_res is None
         dist.barrier()
         q.put(bool(ok))
         dist.destroy_process_group()
@@ -109,12 +109,12 @@ def _worker_packed(rank, world, port, b, q, root_only=False, gather_traj=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("root_only,gather_traj", [(False, True), (True, True), (True, False)])
-def test_packed_gather_two_ranks(root_only, gather_traj):
+@pytest.mark.parametrize("root_only,gather_traj,per", [(False, True, 1), (True, True, 1), (True, False, 1), (True, True, 2), (False, False, 2)])
+def test_packed_gather_two_ranks(root_only, gather_traj, per):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + 7 + 3 * int(root_only) + int(gather_traj)
-    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, 48, q, root_only, gather_traj)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + 7 + 3 * int(root_only) + int(gather_traj) + 11 * per
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, 48, q, root_only, gather_traj, per)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(2)]

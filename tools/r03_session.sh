@@ -136,11 +136,14 @@ g)   # profiles: the default headline, then the same with its early iterations o
 s)   # the soak tests at full size (every instance against the oracle on the box's cores)
   MPC_SOAK=1 timeout -k 10 1100 python -m pytest tests/test_soak.py -m gpu -q -s > $OUT/r03s_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r03s_pytest.log
   ;;
-c)   # collective rehearsal on one GPU: RCCL initialised with a single rank, the per-batch collective inside the timed region
-  for g in root all; do for extra in "" "--gather-results-only"; do
-    timeout -k 10 300 python bench.py --force-collective --gather $g $extra --steps 40 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_${g}${extra:+_ro}.json 2> $OUT/r03c_${g}${extra:+_ro}.err; echo "$g $extra exit=$?" | tee -a $P
-    python -c "import json; r=json.load(open('$OUT/r03c_${g}${extra:+_ro}.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], 'bytes/rank/batch', r['config']['gather_bytes_sent_per_rank_per_batch'])" | tee -a $P
-  done; done
+c)   # collective rehearsal on one GPU: RCCL initialised with a single rank, the collectives inside the timed region
+  timeout -k 10 300 python bench.py --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_none.json 2> $OUT/r03c_none.err
+  python -c "import json; r=json.load(open('$OUT/r03c_none.json')); print('   no collective', r['value']/1e6, 'M solves/s')" | tee -a $P
+  for g in root all; do for grp in 1 4 8; do for extra in "" "--gather-results-only"; do
+    tag=${g}_g${grp}${extra:+_ro}
+    timeout -k 10 300 python bench.py --force-collective --gather $g --gather-group $grp $extra --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_$tag.json 2> $OUT/r03c_$tag.err; echo "$tag exit=$?" | tee -a $P
+    python -c "import json; r=json.load(open('$OUT/r03c_$tag.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], 'bytes/rank/batch', r['config']['gather_bytes_sent_per_rank_per_batch'])" | tee -a $P
+  done; done; done
   timeout -k 10 300 python bench.py --force-collective --population survey --tail-cut 20 --tail-ring 64 --steps 200 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_tails.json 2> $OUT/r03c_tails.err; echo "tails exit=$?" | tee -a $P
   python -c "import json; r=json.load(open('$OUT/r03c_tails.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], r['status_counts'])" | tee -a $P
   timeout -k 10 300 python bench.py --gpus 2 --single-device --backend gloo --steps 20 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_gloo2.json 2> $OUT/r03c_gloo2.err; echo "gloo2 exit=$?" | tee -a $P
@@ -189,6 +192,25 @@ PY
   run n25_f32s_i8 $N25 --inflight 8 --f64-f32-start
   run n25_plain_i8 $N25 --inflight 8
   run n25_plain_i8_c24 $N25 --inflight 8 --tail-cut 24 --tail-ring 64
+  ;;
+c2)  # where does the cost of a collective sit?  one gather for the whole run, and RCCL initialised but never used
+  for grp in 40 80; do
+    timeout -k 10 300 python bench.py --force-collective --gather root --gather-group $grp --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c2_g$grp.json 2> $OUT/r03c2_g$grp.err; echo "g$grp exit=$?" | tee -a $P
+    python -c "import json; r=json.load(open('$OUT/r03c2_g$grp.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'])" | tee -a $P
+  done
+  MPC_BENCH_NO_COLLECTIVE_CALLS=1 timeout -k 10 300 python bench.py --force-collective --gather root --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c2_initonly.json 2> $OUT/r03c2_initonly.err; echo "initonly exit=$?" | tee -a $P
+  python -c "import json; r=json.load(open('$OUT/r03c2_initonly.json')); print('   RCCL initialised, no collective issued:', r['value']/1e6, 'M solves/s')" | tee -a $P
+  timeout -k 10 300 python bench.py --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c2_none.json 2> $OUT/r03c2_none.err
+  python -c "import json; r=json.load(open('$OUT/r03c2_none.json')); print('   no RCCL:', r['value']/1e6, 'M solves/s')" | tee -a $P
+  timeout -k 10 300 python bench.py --force-collective --population survey --tail-cut 20 --tail-ring 64 --steps 200 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c_tails.json 2> $OUT/r03c_tails.err; echo "tails exit=$?" | tee -a $P
+  python -c "import json; r=json.load(open('$OUT/r03c_tails.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'], r['status_counts'])" | tee -a $P
+  ;;
+c3)  # RCCL's kernels take SIMDs from the solve while they run: fewer channels
+  for ch in default 1 2 4; do for grp in 1 4; do
+    if [ $ch = default ]; then E=""; else E="NCCL_MAX_NCHANNELS=$ch NCCL_MIN_NCHANNELS=1"; fi
+    env $E timeout -k 10 300 python bench.py --force-collective --gather root --gather-group $grp --steps 80 --no-legs --no-cpu-baseline --no-host-leg > $OUT/r03c3_ch${ch}_g$grp.json 2> $OUT/r03c3_ch${ch}_g$grp.err; echo "ch$ch g$grp exit=$?" | tee -a $P
+    python -c "import json; r=json.load(open('$OUT/r03c3_ch${ch}_g$grp.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'])" | tee -a $P
+  done; done
   ;;
 esac
 echo done | tee -a $P
