@@ -89,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--tail-ring", type=int, default=32, help="batches whose tails may be outstanding per handle")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (the unfiltered population of the "
                     "headline workload and the other BASELINE.json configs)")
+    ap.add_argument("--leg", default="", help="run ONE extra leg of the default run alone in this process and print its JSON line (what the default "
+                    "run starts as child processes): " + ", ".join(LEGS))
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of an extra leg that does not set its own")
     ap.add_argument("--no-leg-tails", dest="leg_tails", action="store_false", help="run the extra legs without deferred tails")
     ap.add_argument("--population", choices=("filtered", "survey", "unfiltered"), default="filtered",
@@ -315,70 +317,123 @@ def summarize(pkg, np, pipe, B, steps, elapsed):
     return r, status, iters, outs
 
 
-def extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all):
-    """The other populations the driver-timed line reports (VERDICT r2 item 2): the headline workload drawn with SURVEY.md
-    8d's own rejection only, and BASELINE.json configs[1], [3] (one GPU's share) and [4] (one GPU's share).  A few steps each."""
-    legs = {}
+# The extra legs of the default run: name -> (description, keyword arguments of run_leg)
+LEGS = {
+    "unfiltered": ("the headline workload (configs[2]) drawn with SURVEY.md 8d's rejection only (compensated speed above Config::maxSpeed)",
+                   dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=2, population="survey", tail_cut=20, steps=500,
+                        note="28 of the 65 536 instances need 100-400 iterations (9 end at the iteration cap, 19-20 with a failed line search, in the oracle as on "
+                             "the device): their serial chains last 70-100 ms.  Deferred tails (tail_cut 20) take them out of the launches; every batch, stragglers "
+                             "included, is final inside the timed region (the drain of the last tails is part of it)")),
+    "headline_f32_start": ("the headline workload (configs[2]) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above 2e-5) on the fp32 "
+                           "record, every instance finished by the fp64 solver to the same tol and polish; three batches in flight",
+                           dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=3, steps=60, f32_start=True,
+                                note="measured 1.12-1.14x the plain fp64 solve on the same box, below the 1.15x set for making it the default: opt-in "
+                                     "(DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")),
+    "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
+                  dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
+                       note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")),
+    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24, steps=80)),
+    "configs_3_share_f32_start": ("the same share with MpcParams.f64_f32_start = 1 (early iterations on the fp32 record: the long-horizon workspace, 640 KB per wave, "
+                                  "does not fit the Infinity Cache), eight batches in flight",
+                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, steps=80,
+                                       f32_start=True)),
+    "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
+                        "(epsi / v incl. 0 / delta / a)",
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
+                                  "(tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")),
+    "configs_4_share_pure_fp32": ("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), deferred tails",
+                                  dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=24, steps=150,
+                                       f32_pure=True)),
+}
+
+
+def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered",
+            velocity_weights=(0.0, 1.0, 100.0), note=None, tail_cut=0, steps=None, f32_pure=False, f32_start=False, hw_queues=8):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    params = pkg.params_from_json(os.path.join(golden, config), **over)
+    params.f64_f32_start = 1 if f32_start else 0
+    if f32:
+        params.precision = pkg.PRECISION_F32
+        params.f32_finish = 0 if f32_pure else 1
+    if args.max_iter > 0:
+        params.max_iter = args.max_iter
+    tdt = torch.float32 if f32 else torch.float64
+    if kind == "straight":
+        b = pkg.scenarios.straight_line_batch(B, params)
+        b["drawn"], b["rejected"] = B, {}
+    else:
+        b = pkg.scenarios.lake_track_batch(B, params, wp, stream=3, filtered={"filtered": True, "survey": "survey", "unfiltered": False}[population])
+    w = pkg.scenarios.weight_sweep(B, params, seed=1234, velocity_weights=velocity_weights) if sweep else None
+    tens = (t(b["state"], tdt), t(b["coeffs"], tdt), t(b["yaw_lo"], tdt), t(b["yaw_hi"], tdt))
+    steps = steps or args.leg_steps
+    if tail_cut and not args.leg_tails:
+        tail_cut, steps = 0, min(steps, 10)
+    pipe = Pipeline(pkg, torch, params, B, tens, t(w, tdt) if w is not None else None, want_traj, nfl, dev, local_rank, None, args,
+                    tail_cut=tail_cut, tail_ring=64)
+    # warm-up: every handle at least twice (a handle's first call allocates its second workspace / its tail queue)
+    elapsed, ev = timed_run(torch, pipe, steps, 2 * pipe.nfl, sync_all, True)
+    r, _, _, _ = summarize(pkg, np, pipe, B, steps, elapsed)
+    if ev:
+        r["kernel_ms_avg"] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    pipe.close()
+    r.update({"workload": name, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "config": config, "N": params.N, "dt": params.dt, "dtype": "f32" if f32 else "f64", "trajectories": want_traj,
+              "population": population, "draws": int(b["drawn"]), "rejected": b["rejected"]})
+    if note:
+        r["note"] = note
+    return r
 
-    def leg(name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered", velocity_weights=(0.0, 1.0, 100.0), note=None,
-            tail_cut=0, steps=None, f32_pure=False, f32_start=False):
-        params = pkg.params_from_json(os.path.join(golden, config), **over)
-        params.f64_f32_start = 1 if f32_start else 0
-        if f32:
-            params.precision = pkg.PRECISION_F32
-            params.f32_finish = 0 if f32_pure else 1
+
+def extra_legs(args):
+    """The other populations the driver-timed line reports (VERDICT r2 item 2): the headline workload drawn with SURVEY.md
+    8d's own rejection only, and BASELINE.json configs[1], [3] (one GPU's share) and [4] (one GPU's share).  Each leg runs in a
+    child process of its own (`bench.py --leg NAME`): the mapping of a process's streams onto the 8 hardware queues depends on
+    every stream it has created before, and legs run one after the other in one process measured up to 30 % below the same
+    workload run alone.  (The parent has initialised the GPU, so it starts children and never execs.)"""
+    legs = {}
+    for name in LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--leg-steps", str(args.leg_steps)]
         if args.max_iter > 0:
-            params.max_iter = args.max_iter
-        tdt = torch.float32 if f32 else torch.float64
-        if kind == "straight":
-            b = pkg.scenarios.straight_line_batch(B, params)
-            b["drawn"], b["rejected"] = B, {}
-        else:
-            b = pkg.scenarios.lake_track_batch(B, params, wp, stream=3, filtered={"filtered": True, "survey": "survey", "unfiltered": False}[population])
-        w = pkg.scenarios.weight_sweep(B, params, seed=1234, velocity_weights=velocity_weights) if sweep else None
-        tens = (t(b["state"], tdt), t(b["coeffs"], tdt), t(b["yaw_lo"], tdt), t(b["yaw_hi"], tdt))
-        steps = steps or args.leg_steps
-        pipe = Pipeline(pkg, torch, params, B, tens, t(w, tdt) if w is not None else None, want_traj, nfl, dev, local_rank, None, args,
-                        tail_cut=tail_cut if args.leg_tails else 0, tail_ring=64)
-        elapsed, _ = timed_run(torch, pipe, steps, 2, sync_all, False)
-        r, _, _, _ = summarize(pkg, np, pipe, B, steps, elapsed)
-        pipe.close()
-        r.update({"workload": name, "config": config, "N": params.N, "dt": params.dt, "dtype": "f32" if f32 else "f64", "trajectories": want_traj,
-                  "population": population, "draws": int(b["drawn"]), "rejected": b["rejected"]})
-        if note:
-            r["note"] = note
-        return r
-
-    legs["unfiltered"] = leg("the headline workload (configs[2]) drawn with SURVEY.md 8d's rejection only (compensated speed above Config::maxSpeed)",
-                             "config-fast.json", {}, 65536, "lake", False, False, True, 2, population="survey", tail_cut=20, steps=300 if args.leg_tails else 10,
-                             note="28 of the 65 536 instances need 100-400 iterations (9 end at the iteration cap, 19-20 with a failed line search, in the "
-                                  "oracle as on the device): their serial chains last 70-100 ms.  Deferred tails (tail_cut 20) take them out of the launches; "
-                                  "every batch, stragglers included, is final inside the timed region (the drain of the last tails is part of it)")
-    legs["headline_f32_start"] = leg("the headline workload (configs[2]) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above "
-                                     "2e-5) on the fp32 record, every instance finished by the fp64 solver to the same tol and polish; three batches in "
-                                     "flight", "config-fast.json", {}, 65536, "lake", False, False, True, 3, steps=60, f32_start=True,
-                                     note="measured 1.12-1.14x the plain fp64 solve on the same box, below the 1.15x set for making it the default: "
-                                          "opt-in (DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")
-    legs["configs_1"] = leg("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json", "config-stable.json", {}, 4096, "straight",
-                            False, False, True, 8, steps=200,
-                            note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")
-    legs["configs_3_share"] = leg("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",
-                                  "config-stable.json", dict(N=25, dt=0.05), 32768, "lake", False, False, True, 4, tail_cut=24, steps=40)
-    legs["configs_3_share_f32_start"] = leg("the same share with MpcParams.f64_f32_start = 1 (early iterations on the fp32 record: the long-horizon workspace, "
-                                            "640 KB per wave, does not fit the Infinity Cache), eight batches in flight", "config-stable.json", dict(N=25, dt=0.05),
-                                            32768, "lake", False, False, True, 8, steps=40, f32_start=True)
-    legs["configs_4_share"] = leg("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, "
-                                  "per-instance weight sweep (epsi / v incl. 0 / delta / a)", "config-fast.json", {}, 131072, "lake", True, True, False,
-                                  4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance "
-                                  "finished in fp64 (tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")
-    legs["configs_4_share_pure_fp32"] = leg("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), "
-                                            "deferred tails", "config-fast.json", {}, 131072, "lake", True, True, False, 4, tail_cut=24, steps=60, f32_pure=True)
+            cmd += ["--max-iter", str(args.max_iter)]
+        if not args.leg_tails:
+            cmd += ["--no-leg-tails"]
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=str(LEGS[name][1].get("hw_queues", 8)))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            legs[name] = json.loads(line[-1]) if p.returncode == 0 and line else {"workload": LEGS[name][0], "error": (p.stderr or "no output")[-400:]}
+        except Exception as e:                                  # a leg that fails must not take the headline line with it
+            legs[name] = {"workload": LEGS[name][0], "error": repr(e)[:400]}
     return legs
+
+
+def leg_main(args):
+    """`bench.py --leg NAME`: one extra leg alone in this process; prints its JSON line."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(LEGS[args.leg][1].get("hw_queues", 8)))
+    import numpy as np
+    import torch
+    import __graft_entry__ as G
+    pkg = G.load_package()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    golden = os.path.join(ROOT, "tests", "golden")
+    wp = pkg.scenarios.load_waypoints(os.path.join(golden, "lake_track_waypoints.csv"))
+    desc, kw = LEGS[args.leg]
+    r = run_leg(pkg, torch, np, args, dev, 0, golden, wp, lambda: torch.cuda.synchronize(dev), desc, **kw)
+    os.write(json_fd, (json.dumps(r) + "\n").encode())
 
 
 def main():
     args = parse_args()
+    if args.leg:
+        return leg_main(args)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1:
         sys.exit(spawn_ranks(args))                                # before anything touches the GPU
@@ -483,7 +538,8 @@ def main():
 
     # HIP events on the stream the kernel is launched on: torch's current stream, whose handle is what
     # solve_torch passes to mpc_solve_batch_device (a NULL handle is HIP's null stream = torch's default)
-    elapsed, ev = timed_run(torch, pipe, args.steps, args.warmup, sync_all, stub is None)
+    # (a handle's first call allocates lazily -- second workspace, tail queue: at least one untimed step per handle)
+    elapsed, ev = timed_run(torch, pipe, args.steps, max(args.warmup, pipe.nfl), sync_all, stub is None)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -528,7 +584,7 @@ def main():
                    and args.population == "filtered")
     res = {
         "metric": "%sMPC solves/sec (batch) at N=%d dt=%g" % ("STUB (not a measurement) " if stub else "", params.N, params.dt),
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, nfl),
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s%d lake-track states per GPU, 100 ms latency compensation, N=%d dt=%g, %s, trajectories %s%s%s"
@@ -633,7 +689,7 @@ def main():
                                 "b1_note": "one MPC::solve() per telemetry message is what the reference does (mpc_main.cpp:167); includes the ctypes call"}
     pipe.close()
     if world == 1 and stub is None and not args.no_legs:
-        legs = extra_legs(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all)
+        legs = extra_legs(args)
         res["unfiltered"] = legs.pop("unfiltered")
         res["other_configs"] = legs
     if world == 1 and stub is None and not args.no_cpu_baseline:

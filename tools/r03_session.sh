@@ -212,5 +212,35 @@ c3)  # RCCL's kernels take SIMDs from the solve while they run: fewer channels
     python -c "import json; r=json.load(open('$OUT/r03c3_ch${ch}_g$grp.json')); print('  ', r['value']/1e6, 'M solves/s', r['config']['collective_mode'], 'checked', r['config']['gather_checked'])" | tee -a $P
   done; done
   ;;
+u)   # the long-horizon legs: does the step count explain the gap between the default run's legs and the standalone runs?
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03u_$tag.json 2> $OUT/r03u_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03u_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768"
+  for st in 40 80 160; do run n25_f32s_i8_s$st $N25 --inflight 8 --f64-f32-start --steps $st; done
+  for st in 40 80 160; do run n25_plain_i4_c24_s$st $N25 --inflight 4 --tail-cut 24 --tail-ring 64 --steps $st; done
+  ;;
+v)   # one leg alone, with and without HIP events around its launches
+  for k in 1 2; do
+    python bench.py --leg headline_f32_start 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   events   ', r['solves_per_s']/1e6, r.get('kernel_ms_avg'))" | tee -a $P
+    MPC_BENCH_LEG_NO_EVENTS=1 python bench.py --leg headline_f32_start 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   no events', r['solves_per_s']/1e6)" | tee -a $P
+    python bench.py --f64-f32-start --inflight 3 --steps 60 --no-legs --no-cpu-baseline --no-host-leg 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   main path', r['value']/1e6)" | tee -a $P
+  done
+  ;;
+w)   # main path vs leg path of the same workload: which difference matters?
+  m() { python bench.py --f64-f32-start --inflight 3 --steps 60 --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   main', '$*', r['value']/1e6, 'queues', r['config']['hw_queues'])" | tee -a $P; }
+  m
+  GPU_MAX_HW_QUEUES=4 m
+  GPU_MAX_HW_QUEUES=8 m
+  m --warmup 2
+  m --tail-ring 64
+  python bench.py --leg headline_f32_start 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   leg (queues 4 set)', r['solves_per_s']/1e6)" | tee -a $P
+  ;;
 esac
 echo done | tee -a $P
