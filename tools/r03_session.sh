@@ -242,5 +242,24 @@ w)   # main path vs leg path of the same workload: which difference matters?
   m --tail-ring 64
   python bench.py --leg headline_f32_start 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   leg (queues 4 set)', r['solves_per_s']/1e6)" | tee -a $P
   ;;
+x)   # configs[3] and configs[4]: the FULL batch on one GPU
+  run() { tag=$1; shift; timeout -k 10 600 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03x_$tag.json 2> $OUT/r03x_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03x_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  C3="--N 25 --dt 0.05 --config config-stable.json --batch 262144 --steps 12 --warmup 4"
+  run cfg3_full_plain $C3 --inflight 2
+  run cfg3_full_tails $C3 --inflight 2 --tail-cut 24 --tail-ring 16
+  run cfg3_full_f32start $C3 --inflight 3 --f64-f32-start
+  C4="--weights-sweep --precision f32 --no-traj --batch 1048576 --steps 12 --warmup 4"
+  run cfg4_full_mixed $C4 --inflight 2
+  run cfg4_full_pure $C4 --inflight 2 --f32-pure
+  run cfg4_full_pure_tails $C4 --inflight 2 --f32-pure --tail-cut 24 --tail-ring 16
+  ;;
 esac
 echo done | tee -a $P
