@@ -883,6 +883,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   return MPC_OK;
 }
 
+static int tail_flush(MpcHandle *h, int si);
+
 extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
   int rc = validate_params(p);
@@ -893,6 +895,14 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
   if (h->tail_ready && (p->tail_ring != h->params.tail_ring || p->tail_capacity != h->params.tail_capacity)) {
     g_last_error = "tail_ring and tail_capacity cannot change once the tail queue exists"; return MPC_ERR_INVALID;
+  }
+  if (h->tail_ready) {
+    /* stragglers of earlier batches are finished under the parameters their batch was issued with: every tail launch
+     * takes the handle's parameters by value when it goes out, so what is still queued goes out, and completes, first */
+    MPC_ON_DEVICE(h);
+    const int rf = tail_flush(h, -1);
+    if (rf != MPC_OK) return rf;
+    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
   }
   h->params = *p;
   set_cuts(h, p);
@@ -1017,7 +1027,7 @@ static int tail_prepare(MpcHandle *h) {
 
 /* Tail launches for every deferred batch that none serves yet (kTailPerLaunch batches per launch), on tail stream `si`
  * (-1: the first idle one, else the one whose launch is the oldest) */
-static int tail_flush(MpcHandle *h, int si = -1) {
+static int tail_flush(MpcHandle *h, int si) {
   if (!h->tail_ready) return MPC_OK;
   int order[kTailMaxRing];
   int n = 0;
@@ -1100,7 +1110,7 @@ extern "C" int64_t mpc_last_batch_id(const MpcHandle *h) { return h ? h->batch_s
 extern "C" int mpc_tail_flush(MpcHandle *h) {
   if (!h) return MPC_ERR_INVALID;
   MPC_ON_DEVICE(h);
-  return tail_flush(h);
+  return tail_flush(h, -1);
 }
 
 extern "C" int mpc_tail_wait(MpcHandle *h, int64_t batch_id) {
@@ -1108,14 +1118,14 @@ extern "C" int mpc_tail_wait(MpcHandle *h, int64_t batch_id) {
   if (!h->tail_ready) return MPC_OK;
   MPC_ON_DEVICE(h);
   if (batch_id <= 0) {                         /* everything handed over so far */
-    const int rf = tail_flush(h);
+    const int rf = tail_flush(h, -1);
     if (rf != MPC_OK) return rf;
     for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
     return MPC_OK;
   }
   MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
   if (!S) return MPC_OK;
-  if (S->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+  if (S->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
   if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;     /* its event has been recycled: that launch is long done */
   MPC_HIP_CHECK(hipEventSynchronize(h->tail_ev[S->launch % kTailMaxRing]));
   return MPC_OK;
@@ -1127,7 +1137,7 @@ extern "C" int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream
   MPC_ON_DEVICE(h);
   MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
   if (!S) return MPC_OK;
-  if (S->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+  if (S->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
   if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;
   MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->tail_ev[S->launch % kTailMaxRing], 0));
   return MPC_OK;
@@ -1240,7 +1250,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (ts->batch_id != 0) {
       /* the queue slot is taken again: whatever it held must have been served (if the tails are slower than ring x
        * batches, this is where the caller's stream waits for them) */
-      if (ts->launch < 0) { const int rf = tail_flush(h); if (rf != MPC_OK) return rf; }
+      if (ts->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
       MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->tail_ev[ts->launch % kTailMaxRing], 0));
     }
     MPC_HIP_CHECK(hipMemsetAsync(h->d_tcount + slot_index, 0, sizeof(int32_t), (hipStream_t)stream_));
@@ -1474,7 +1484,7 @@ extern "C" int mpc_synchronize(MpcHandle *h) {
   MPC_ON_DEVICE(h);
   MPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (h->tail_ready) {
-    const int rf = tail_flush(h);
+    const int rf = tail_flush(h, -1);
     if (rf != MPC_OK) return rf;
     for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
   }

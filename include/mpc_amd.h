@@ -166,6 +166,8 @@ int mpc_params_load_json(const char *path, MpcParams *p);
  * To keep several batches in flight -- which is how to fill the device, see DESIGN.md section 6b -- create one
  * handle per stream. */
 int mpc_create(const MpcParams *p, int device, int64_t max_batch, MpcHandle **out);
+/* (N, precision and the mixed-precision switches size the workspaces and cannot change on a live handle; with deferred tails
+ * outstanding the call first lets them finish under the parameters their batches were issued with) */
 int mpc_set_params(MpcHandle *h, const MpcParams *p);
 void mpc_destroy(MpcHandle *h);
 const char *mpc_last_error(void);

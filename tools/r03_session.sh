@@ -261,5 +261,19 @@ PY
   run cfg4_full_pure $C4 --inflight 2 --f32-pure
   run cfg4_full_pure_tails $C4 --inflight 2 --f32-pure --tail-cut 24 --tail-ring 16
   ;;
+y)   # does lane refill pay on the fp32 kernel (less traffic-bound than the fp64 one)?
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03y_$tag.json 2> $OUT/r03y_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03y_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  kernel_ms %.3f alone %.3f" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["roofline"]["kernel_ms_avg"], r["roofline"]["kernel_ms_alone"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  F="--precision f32 --f32-pure --steps 100"
+  for ipl in 1 2 4; do for i in 2 4 6; do MPC_INSTANCES_PER_LANE=$ipl run f32pure_ipl${ipl}_i$i $F --inflight $i; done; done
+  for ipl in 2 4; do MPC_INSTANCES_PER_LANE=$ipl MPC_REFILL_MIN=4 MPC_REFILL_WAIT=2 run f32pure_ipl${ipl}_i4_eager $F --inflight 4; done
+  ;;
 esac
 echo done | tee -a $P
