@@ -612,3 +612,34 @@ def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_
                 assert all(0 < x for x in live[-1:]) or cut > 8, (case, cut, live)     # (passes count from the start of the fp64 phase)
             else:
                 assert all(x == 256 for x in live), (case, live)    # the queue filled up; everything else finished in its launch
+
+
+def test_deferred_tails_finish_under_their_batchs_parameters(pkg, golden_dir, waypoints, torch_dev):
+    """mpc_set_params between two batches: the stragglers of the first batch, still queued, are finished under the parameters
+    that batch was issued with (here: the iteration cap), the second batch runs under the new ones."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 8192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=71)
+    w = pkg.scenarios.weight_sweep(B, params, seed=72, velocity_weights=(0.0, 1.0, 100.0))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev)
+    ins = [t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"])]
+    capped = params.copy(); capped.max_iter = 12
+    ref = {}
+    for name, p in (("full", params), ("capped", capped)):
+        with pkg.BatchedMPC(p, B, device=0) as mpc:
+            r = mpc.solve_torch(*ins, weights=t(w)); torch.cuda.synchronize()
+            ref[name] = {k: v.cpu().numpy() for k, v in r.items() if v is not None}
+    assert (ref["capped"]["status"] == 1).sum() > 100 and (ref["full"]["status"] == 0).all()
+    p1 = params.copy(); p1.tail_cut = 8
+    p2 = capped.copy(); p2.tail_cut = 8
+    with pkg.BatchedMPC(p1, B, device=0) as mpc:
+        o1, o2 = mpc.alloc_outputs(B, torch_dev), mpc.alloc_outputs(B, torch_dev)
+        mpc.solve_torch(*ins, weights=t(w), outputs=o1)
+        assert mpc.tail_pending(mpc.last_batch_id()) > 100           # stragglers of batch 1 are queued ...
+        mpc.set_params(p2)                                           # ... and must not see the new cap
+        mpc.solve_torch(*ins, weights=t(w), outputs=o2)
+        mpc.tail_wait(0); torch.cuda.synchronize()
+        for k in ("out", "status", "iters"):
+            assert np.array_equal(o1[k].cpu().numpy(), ref["full"][k], equal_nan=True), k
+            assert np.array_equal(o2[k].cpu().numpy(), ref["capped"][k], equal_nan=True), k
