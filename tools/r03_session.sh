@@ -275,5 +275,20 @@ PY
   for ipl in 1 2 4; do for i in 2 4 6; do MPC_INSTANCES_PER_LANE=$ipl run f32pure_ipl${ipl}_i$i $F --inflight $i; done; done
   for ipl in 2 4; do MPC_INSTANCES_PER_LANE=$ipl MPC_REFILL_MIN=4 MPC_REFILL_WAIT=2 run f32pure_ipl${ipl}_i4_eager $F --inflight 4; done
   ;;
+z)   # waves per tail launch on the SURVEY population (few stragglers per batch, 28 of them with very long chains)
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r03z_$tag.json 2> $OUT/r03z_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03z_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  kernel_ms %.3f  tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["roofline"]["kernel_ms_avg"], r["config"]["deferred_tails"]["tail_launches"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  S="--population survey --tail-cut 20 --tail-ring 64 --steps 500"
+  for w in 8 16 32 64 128 256; do MPC_TAIL_WAVES=$w run survey_w$w $S; done
+  MPC_TAIL_WAVES=32 run survey_w32_c16 --population survey --tail-cut 16 --tail-ring 64 --steps 500
+  MPC_TAIL_WAVES=32 MPC_TAIL_STREAMS=3 run survey_w32_st3 $S
+  ;;
 esac
 echo done | tee -a $P
