@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--f64-f32-start", action="store_true", help="fp64 handle with MpcParams.f64_f32_start = 1: the early iterations on the fp32 "
                     "record, every instance finished by the fp64 solver (experimental)")
     ap.add_argument("--switch-mu", type=float, default=0.0, help="MpcParams.mixed_switch_mu (default 2e-5)")
+    ap.add_argument("--tol-f32", type=float, default=0.0, help="MpcParams.tol_f32 (default 5e-4): where the fp32 phase of a mixed-precision solve hands "
+                    "over at the latest, and the stopping rule of the pure fp32 mode")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline legs (one thread + all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive and B=1 latency measurements")
@@ -497,6 +499,8 @@ def main():
     params.f64_f32_start = 1 if args.f64_f32_start else 0
     if args.switch_mu > 0:
         params.mixed_switch_mu = args.switch_mu
+    if args.tol_f32 > 0:
+        params.tol_f32 = args.tol_f32
     if args.max_iter > 0:
         params.max_iter = args.max_iter
     cuts = [int(c) for c in args.pass_cuts.split(",") if c.strip()][:4]

@@ -290,5 +290,25 @@ PY
   MPC_TAIL_WAVES=32 run survey_w32_c16 --population survey --tail-cut 16 --tail-ring 64 --steps 500
   MPC_TAIL_WAVES=32 MPC_TAIL_STREAMS=3 run survey_w32_st3 $S
   ;;
+h)   # where should the fp32 phase of the fp64 headline hand over?  (tol_f32 = the E_0 at which it does, switch_mu = the barrier value)
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --f64-f32-start --inflight 3 --steps 100 "$@" > $OUT/r03h_$tag.json 2> $OUT/r03h_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03h_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  run default
+  run tol1e-3 --tol-f32 1e-3
+  run tol2e-4 --tol-f32 2e-4
+  run tol1e-4 --tol-f32 1e-4
+  run tol1e-4_mu2e-6 --tol-f32 1e-4 --switch-mu 2e-6
+  run tol5e-5_mu2e-6 --tol-f32 5e-5 --switch-mu 2e-6
+  run tol2e-4_mu5e-6 --tol-f32 2e-4 --switch-mu 5e-6
+  run default_again
+  timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   plain fp64               ', r['value']/1e6)" | tee -a $P
+  ;;
 esac
 echo done | tee -a $P
