@@ -1005,21 +1005,22 @@ static int tail_prepare(MpcHandle *h) {
   if (const char *e = getenv("MPC_TAIL_STREAMS")) h->n_tail_streams = atoi(e);
   if (h->n_tail_streams < 1) h->n_tail_streams = 1;
   if (h->n_tail_streams > kTailMaxStreams) h->n_tail_streams = kTailMaxStreams;
-  for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream[q], hipStreamNonBlocking, prio));
+  for (int q = 0; q < h->n_tail_streams; q++)
+    if (!h->tail_stream[q]) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream[q], hipStreamNonBlocking, prio));
   const int64_t K = h->tail_ring, cp = h->tail_cap;
   const int M = P.N - 1;
   const size_t it_sz = f32 ? (size_t)mpc::Fields<float>::IT_SZ : (size_t)mpc::Fields<double>::IT_SZ;
   h->titer_slot_bytes = (size_t)(cp / 64) * M * it_sz * 64 * real_bytes;
-  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * kTailMaxRing));
+  if (!h->d_tcount) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * kTailMaxRing));
   MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * kTailMaxRing));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->d_ttake, sizeof(int32_t) * kTailMaxRing));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tinst, sizeof(int32_t) * K * cp));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->d_tpark, sizeof(double) * K * kTailRows * cp));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->d_titer, h->titer_slot_bytes * K));
-  MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
+  if (!h->d_ttake) MPC_HIP_CHECK(hipMalloc((void **)&h->d_ttake, sizeof(int32_t) * kTailMaxRing));
+  if (!h->d_tinst) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tinst, sizeof(int32_t) * K * cp));
+  if (!h->d_tpark) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tpark, sizeof(double) * K * kTailRows * cp));
+  if (!h->d_titer) MPC_HIP_CHECK(hipMalloc((void **)&h->d_titer, h->titer_slot_bytes * K));
+  if (!h->tail_ws) MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
   for (int q = 0; q < kTailMaxRing; q++) {
-    MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tslot[q].bulk, hipEventDisableTiming));
-    MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tail_ev[q], hipEventDisableTiming));
+    if (!h->tslot[q].bulk) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tslot[q].bulk, hipEventDisableTiming));
+    if (!h->tail_ev[q]) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tail_ev[q], hipEventDisableTiming));
   }
   h->tail_ready = true;
   return MPC_OK;
@@ -1175,13 +1176,14 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
                         const RIO *yaw_hi, const RIO *weights, RIO *out, RIO *traj, int32_t *status, int32_t *iters, hipStream_t s,
                         const MpcPhase &tail) {
   const int64_t tiles = h->io_stride / 64;
+  /* h->ws holds the handle's own layout; the phases need one workspace of each (each allocation on its own: a failure
+   * leaves the handle usable for a retry, and mpc_destroy frees whatever exists) */
   if (!h->ws2) {
-    /* h->ws holds the handle's own layout; the phases need one workspace of each */
     const size_t other = sizeof(RIO) == 4 ? (size_t)h->ws_stride_f64 * tiles * sizeof(double) : (size_t)h->ws_stride_f32 * tiles * sizeof(float);
     MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, other));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
   }
+  if (!h->d_park) MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
+  if (!h->d_list) MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
   float *ws32 = sizeof(RIO) == 4 ? (float *)h->ws : (float *)h->ws2;
   double *ws64 = sizeof(RIO) == 4 ? (double *)h->ws2 : (double *)h->ws;
   int32_t *it_out = iters ? iters : h->d_iters;
@@ -1283,11 +1285,11 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
     return MPC_OK;
   }
-  if (n_cuts > 0 && !h->ws2) {
+  if (n_cuts > 0) {
     const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * sizeof(R);
-    MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
+    if (!h->ws2) MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
+    if (!h->d_park) MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
+    if (!h->d_list) MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
   }
   if (h->lds_lanes > 0 && B <= h->lds_max_batch) {
     MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
