@@ -643,3 +643,57 @@ def test_deferred_tails_finish_under_their_batchs_parameters(pkg, golden_dir, wa
         for k in ("out", "status", "iters"):
             assert np.array_equal(o1[k].cpu().numpy(), ref["full"][k], equal_nan=True), k
             assert np.array_equal(o2[k].cpu().numpy(), ref["capped"][k], equal_nan=True), k
+
+
+def test_deferred_tails_stress_changing_batches_two_handles(pkg, golden_dir, waypoints, torch_dev):
+    """Two handles on two streams, 40 batches of changing size (some below the size at which a handle defers at all) issued
+    without a pause through a ring of 4 queue slots, consumers waiting through mpc_tail_stream_wait in issue order and out of
+    it: every batch bitwise what an undisturbed launch of the same instances gives."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    BMAX = 16384
+    b = pkg.scenarios.lake_track_batch(BMAX, params, waypoints, seed=91)
+    w = pkg.scenarios.weight_sweep(BMAX, params, seed=92, velocity_weights=(0.0, 1.0, 100.0))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev)
+    with pkg.BatchedMPC(params, BMAX, device=0) as mpc:
+        ref = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w), want_traj=True)
+        torch.cuda.synchronize()
+        ref = {k: v.cpu().numpy() for k, v in ref.items()}
+    p = params.copy(); p.tail_cut = 10; p.tail_ring = 4
+    rng = np.random.default_rng(5)
+    hs = [pkg.BatchedMPC(p, BMAX, device=0) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=torch_dev, priority=-1) for _ in hs]
+    consumer = torch.cuda.Stream(device=torch_dev)
+    jobs = []
+    try:
+        for n in range(40):
+            B = int(rng.choice([1500, 4096, 5000, 8192, 12345, 16384]))
+            lo = int(rng.integers(0, BMAX - B + 1))
+            h, s = hs[n & 1], streams[n & 1]
+            sl = slice(lo, lo + B)
+            ins = [t(b["state"][:, sl]), t(b["coeffs"][:, sl]), t(b["yaw_lo"][sl]), t(b["yaw_hi"][sl])]
+            with torch.cuda.stream(s):
+                o = h.solve_torch(*ins, weights=t(w[:, sl]), want_traj=True)
+            jobs.append((h, h.last_batch_id(), lo, B, o, ins))
+        order = list(range(40))
+        rng.shuffle(order)
+        sums = {}
+        for k in order:                                               # consumers wait on their own stream, in any order
+            h, bid, lo, B, o, _ = jobs[k]
+            h.tail_stream_wait(bid, consumer)
+            with torch.cuda.stream(consumer):
+                sums[k] = o["out"][6].sum()
+        for h in hs:
+            h.tail_wait(0)
+        torch.cuda.synchronize()
+        deferred = 0
+        for k, (h, bid, lo, B, o, _) in enumerate(jobs):
+            for key in ("status", "iters", "out", "traj"):
+                assert np.array_equal(o[key].cpu().numpy(), ref[key][..., lo:lo + B], equal_nan=True), (k, B, key)
+            assert float(sums[k]) == float(o["out"][6].sum())           # what the consumer read behind the tail's event was final
+            deferred += B >= 4096
+        info = [h.tail_info() for h in hs]
+        assert sum(i["batches_deferred"] for i in info) == deferred and all(i["ring"] == 4 for i in info)
+    finally:
+        for h in hs:
+            h.close()
