@@ -697,3 +697,27 @@ def test_deferred_tails_stress_changing_batches_two_handles(pkg, golden_dir, way
     finally:
         for h in hs:
             h.close()
+
+
+@pytest.mark.parametrize("config,over,B", [("config-fast.json", {}, 4096), ("config-stable.json", dict(N=25, dt=0.05), 1024)])
+def test_fp32_start_of_the_fp64_solve_matches_oracle(pkg, golden_dir, waypoints, torch_dev, config, over, B):
+    """MpcParams.f64_f32_start = 1: the early iterations on the fp32 record, every instance finished by the fp64 solver.  Same
+    stated fp64 tolerances against the oracle (the returned point is defined by tol and the polish, not by the path), same
+    statuses, about the same number of iterations, and against the single-phase solve of the same handle type within 1e-6."""
+    params = pkg.params_from_json(os.path.join(golden_dir, config), **over)
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=97)
+    w = pkg.scenarios.weight_sweep(B, params, seed=98, velocity_weights=(0.0, 1.0, 100.0))
+    plain = gpu_solve(pkg, params, b, torch_dev, weights=w)
+    p = params.copy(); p.f64_f32_start = 1
+    r = gpu_solve(pkg, p, b, torch_dev, weights=w)
+    assert np.array_equal(r["status"], plain["status"])
+    ok = r["status"] == 0
+    assert ok.mean() > 0.99
+    # forks onto another local minimum (flat objectives: velocity weight 0) are counted like in the fp32 mode's tests
+    far = ok & ((np.abs(r["out"][6] - plain["out"][6]) > 1e-6) | (np.abs(r["out"][7] - plain["out"][7]) > 1e-5) | (np.abs(r["out"][:6] - plain["out"][:6]).max(0) > 1e-5))
+    assert far.sum() <= max(1, B // 2000), np.where(far)[0][:8]
+    assert abs(r["iters"][ok].mean() - plain["iters"][ok].mean()) < 0.5
+    idx = [int(i) for i in np.where(ok & ~far)[0][::max(1, B // 128)]]
+    ref = oracle_solve_batch(O.load_config(config, **over), b, idx, weights=w)
+    assert (ref["status"] == 0).all()
+    assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "fp32 start, %s" % config)
