@@ -1375,6 +1375,7 @@ struct Solver {
    * tol_f32, or its line search has run out of single precision): step() returns MPC_PROMOTE at a pass boundary, the
    * instance is parked (park()), and an fp64 solver takes the iterate over (unpark() + promoted()): it re-evaluates the
    * point in fp64 and carries on with the same state machine to tol and the polish. */
+  static constexpr bool kCanPromote = sizeof(R) == 4;   /* only the fp32 solver ever hands over: none of it is in the fp64 kernels */
   R promote_mu = R(0.0);
   bool keep_theta = false;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
@@ -1463,7 +1464,7 @@ struct Solver {
    * rounding into the dual residual, slacks of a few ulp cannot shrink), so a point whose optimality error is within
    * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
   MPC_HD int line_search_failed() const {
-    if (promote_mu > R(0.0)) return MPC_PROMOTE;   /* out of step length in single precision: the iterate goes on in fp64 */
+    if ((kCanPromote && promote_mu > R(0.0))) return MPC_PROMOTE;   /* out of step length in single precision: the iterate goes on in fp64 */
     if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
     /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
     if (n_polish > 0 && kkt_error(E, R(0.0)) <= tol) return MPC_STATUS_SUCCESS;
@@ -1491,7 +1492,7 @@ struct Solver {
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
         /* as far as this precision is asked to go -- or an instance that is taking long: the stragglers (steps of a few per
          * cent against a bound for dozens of iterations) are where the noise of fp32 steps costs most; they go on in fp64 */
-        if (promote_mu > R(0.0) && (E0 <= tol || iter >= kPromoteIterCap)) return MPC_PROMOTE;
+        if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= kPromoteIterCap)) return MPC_PROMOTE;
         if (E0 <= tol) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
@@ -1512,7 +1513,7 @@ struct Solver {
           tau = mpc_max(IC::tau_min, R(1.0) - mu);
           nf = 0;
         }
-        if (promote_mu > R(0.0) && mu <= promote_mu) return MPC_PROMOTE;   /* the barrier problems below are the other solver's */
+        if ((kCanPromote && promote_mu > R(0.0)) && mu <= promote_mu) return MPC_PROMOTE;   /* the barrier problems below are the other solver's */
 #if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
         printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
                E.dinf, E.cmin, E.cmax, mu, E0, nf);
@@ -1527,7 +1528,7 @@ struct Solver {
         if (lsm) { okb = false; break; }
         if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
         else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
-        if (dw > IC::dw_max || ++tries > 100) return promote_mu > R(0.0) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH;
+        if (dw > IC::dw_max || ++tries > 100) return (kCanPromote && promote_mu > R(0.0)) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH;
       }
       if (okb) forward();
       dw_cur = dw;
