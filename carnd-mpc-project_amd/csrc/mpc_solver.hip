@@ -821,6 +821,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true) * 64;
   h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false) * 64;
   h->mixed = f32 ? p->f32_finish != 0 : p->f64_f32_start != 0;
+  /* MPC_MIXED=0/1 overrides the parameter for every handle of the process: how the whole parity suite was run with the fp32
+   * start forced on (tools/r03_session.sh p); a measurement aid, not an interface */
   if (const char *e = getenv("MPC_MIXED")) h->mixed = atoi(e) != 0;
   if (h->mixed) {
     MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1, float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
