@@ -605,6 +605,7 @@ def main():
                    "mixed_precision": ("fp32 iterations to mu = %g, every instance finished in fp64" % params.mixed_switch_mu) if ((f32 and params.f32_finish) or
                                                                                                                                 (not f32 and params.f64_f32_start)) else "no",
                    "deferred_tails": summary.get("tails", "off"), "tail_cut": pipe.tail,
+                   "lane_compact": int(os.environ.get("MPC_LANE_COMPACT", params.lane_compact)) if B >= 8192 else 0,
                    # the generator redraws instances the reference's own road model does not hold for (scenarios.py); the
                    # `unfiltered` leg below is the same workload without that
                    "population": args.population,

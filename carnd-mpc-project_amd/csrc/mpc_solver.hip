@@ -122,6 +122,13 @@ struct MpcPhase {
    * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
    * waiting, or `refill_wait` passes have gone by, or nothing else is running; then all of them are served at once. */
   int32_t refill_min, refill_wait;
+  /* Lane compaction (MPC_LANE_COMPACT=gap, measurement aid).  Memory is fetched in 128-byte lines = the 16-byte groups of 8
+   * neighbouring lanes, so a line is fetched as long as ONE of its 8 lanes still runs (tools/traffic_model.py: the launch
+   * fetches 1.24 x what its running lanes ask for).  Once the launch's counter is exhausted, a wave whose running lanes are
+   * spread over `compact_gap` more 8-lane groups than they need moves the ones outside its fullest groups into free lanes
+   * inside them: solver scalars through LDS (the staging buffers are idle between passes), set-up repeated from the inputs,
+   * the iterate copied column to column -- the arithmetic of an instance does not depend on its lane. */
+  int32_t compact_gap;
   /* Tile pool (MpcTilePool, optional): instead of tile number blockIdx of the handle's own workspace a wave takes a free
    * tile from the pool of ITS XCD and gives it back when it leaves, so that the addresses the device cycles through are
    * the tiles of the resident waves and not those of every batch in flight. */
@@ -204,13 +211,37 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   int64_t i = 0;
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
   bool queue_full = false;                       /* deferred tails: the batch's queue slot has no room left */
-  int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0;
+  bool col_busy = false;                         /* this lane's column holds a parked iterate */
+  int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0, cooldown = 0;
   const int64_t n_work = T.resume ? (int64_t)*T.n_in : B;
+  (void)col_busy; (void)cooldown;
   for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* ---- lane compaction, part 1: is it worth it now?  (see MpcPhase.compact_gap) ---- */
+    bool want_compact = false;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_min = 0;
+    if (STAGING && T.compact_gap > 0) {
+      if (MPC_WAVE_ANY(more) && (int64_t)__hip_atomic_load(T.take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_work) more = false;
+      if (!MPC_WAVE_ANY(more)) {
+        if (cooldown > 0) --cooldown;
+        else {
+          const unsigned long long live = __builtin_amdgcn_ballot_w64(have);
+          const int nl = __builtin_popcountll(live);
+          int g_now = 0;
+#pragma unroll
+          for (int g = 0; g < 8; g++) { cnt[g] = __builtin_popcountll((live >> (8 * g)) & 0xffull); g_now += cnt[g] > 0 ? 1 : 0; }
+          g_min = (nl + 7) >> 3;
+          want_compact = nl > 0 && g_now - g_min >= T.compact_gap;
+        }
+      }
+    }
+#else
+    const bool want_compact = false;
+#endif
     /* ---- hand-over point (wave-uniform decision, see MpcPhase) ---- */
     const int n_wait = MPC_WAVE_COUNT(fin || (!have && more));
     if (n_wait > 0) {
-      if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait) {
+      if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait || want_compact) {
         waited = 0;
         if (fin) {
           RIO *o = out + i;
@@ -222,9 +253,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           if (iters) iters[i] = S.iters + it_total;
           fin = false;
         }
+        bool exhausted = false;
         if (!have && more) {
           const int64_t pos = (int64_t)atomicAdd(T.take, 1);
           more = pos < n_work;
+          exhausted = !more;
           if (more) {
             i = T.resume ? (int64_t)T.in_inst[pos] : pos;
             R st[6], cf[MPC_NCOEF], w[MPC_NW];
@@ -282,8 +315,76 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
                                                                                * bounds): the start point is reported at the next hand-over */
           }
         }
+        if (MPC_WAVE_ANY(exhausted)) more = false;   /* the counter only grows: what one lane found empty is empty for all */
       } else ++waited;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* ---- lane compaction, part 2 (finished lanes have just been served: their columns are free) ---- */
+    if (want_compact) {
+      unsigned long long keep = 0;               /* the g_min fullest groups stay where they are */
+      for (int t = 0; t < g_min; ++t) {
+        int best = 0, bc = -1;
+#pragma unroll
+        for (int g = 0; g < 8; g++) if (!((keep >> (8 * g)) & 1ull) && cnt[g] > bc) { bc = cnt[g]; best = g; }
+        keep |= 0xffull << (8 * best);
+      }
+      const bool in_keep = (keep >> threadIdx.x) & 1ull;
+      const bool movable = have && S.phase == SV::PH_DIR && !in_keep;
+      const bool is_free = !have && !fin && !col_busy && in_keep;
+      const unsigned long long mv = __builtin_amdgcn_ballot_w64(movable), fr = __builtin_amdgcn_ballot_w64(is_free);
+      const int n_mv = __builtin_popcountll(mv), n_fr = __builtin_popcountll(fr);
+      const int n = n_mv < n_fr ? n_mv : n_fr;
+      if (n > 0) {
+        ws.stage_drain();                        /* the trial sweep's stores have landed, the staging buffers are idle */
+        double *mb = smem;                       /* [38][64]: Solver::park scalars, instance, passes */
+        const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+        const bool is_src = movable && __builtin_popcountll(mv & below) < n;
+        const int my_f = __builtin_popcountll(fr & below);
+        const bool is_dst = is_free && my_f < n;
+        if (is_src) {
+          const unsigned ln = threadIdx.x;
+          S.park([mb, ln](int q) -> double & { return mb[q * 64 + ln]; }, attempt, it_total);
+          mb[36 * 64 + ln] = (double)i; mb[37 * 64 + ln] = (double)passes;
+          have = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (is_dst) {
+          unsigned long long m = mv;
+          for (int r = 0; r < my_f; ++r) m &= m - 1ull;
+          const int src = __builtin_ctzll(m);
+          i = (int64_t)mb[36 * 64 + src]; passes = (int)mb[37 * 64 + src];
+          R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+          for (int q = 0; q < 6; q++) st[q] = (R)state[q * ld + i];
+#pragma unroll
+          for (int q = 0; q < MPC_NCOEF; q++) cf[q] = (R)coeffs[q * ld + i];
+          if (weights) {
+#pragma unroll
+            for (int q = 0; q < MPC_NW; q++) w[q] = (R)weights[q * ld + i];
+          } else {
+#pragma unroll
+            for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
+          }
+          (void)S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, false);
+          S.unpark([mb, src](int q) -> double { return mb[q * 64 + src]; }, attempt, it_total);
+          const int I = S.cur ? FL::IT1 : FL::IT0;
+          WS wsrc = ws;
+          wsrc.lane = src;
+          for (int k = 0; k < P.N - 1; ++k) {
+            R rec[FL::IT_SZ];
+#pragma unroll
+            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = __hip_atomic_load(&wsrc.it(k, I, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+          }
+          have = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+        cooldown = 2;
+      }
+    }
+#endif
     if (!MPC_WAVE_ANY(have || more || fin)) break;
     if (have) {
       const int r = S.step();
@@ -299,7 +400,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         const int64_t lp = T.ld_park;
         S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
         pk[35 * lp] = r == SV::MPC_PROMOTE ? 0.0 : 1.0;
-        have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
+        have = false; more = false; col_busy = true;     /* the column keeps the parked iterate: this lane takes nothing else */
       } else if (r != SV::MPC_RUNNING) {
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
@@ -337,7 +438,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         double *pk = T.out_park + pos;
         const int64_t lp = T.ld_park;
         S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
-        have = false; more = false;     /* the column keeps the parked iterate: this lane takes nothing else */
+        have = false; more = false; col_busy = true;     /* the column keeps the parked iterate: this lane takes nothing else */
       }
     }
   }
@@ -682,6 +783,12 @@ struct MpcHandle {
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
   int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
+  int compact_gap = 0;        /* MpcParams.lane_compact, or MPC_LANE_COMPACT in the environment (measurement aid): see MpcPhase.compact_gap */
+  bool compact_env = false;
+  int64_t compact_min_batch = 8192;   /* smaller launches are latency-bound: the moves cost more than the lines they save */
+  int finish_div = 1;         /* mixed precision: the fp64 phase runs ceil(waves / finish_div) waves whose lanes take the promoted
+                               * instances in turn (MPC_FINISH_DIV) */
+  int finish_refill_min = 16, finish_refill_wait = 8;   /* its hand-over policy (MPC_FINISH_REFILL_MIN / _WAIT) */
   /* multi-phase solve: second workspace, two parked-instance lists and two sets of scalars (allocated on first use) */
   int n_cuts = 0;             /* MpcParams.pass_cut + pass_cut_next[], or MPC_PASS_CUT=a,b,c,d in the environment (none = single launch) */
   int cuts[kMaxCuts] = {0, 0, 0, 0};
@@ -752,6 +859,7 @@ static int validate_params(const MpcParams *p) {
   if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
   if (p->tail_cut < 0 || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
+  if (p->lane_compact < 0 || p->lane_compact > 7) { g_last_error = "lane_compact must be 0 (off) .. 7"; return MPC_ERR_INVALID; }
   return MPC_OK;
 }
 
@@ -882,6 +990,11 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (const char *e4 = getenv("MPC_REFILL_MIN")) { h->refill_min = atoi(e4); if (h->refill_min < 1) h->refill_min = 1; }
   if (const char *e5 = getenv("MPC_REFILL_WAIT")) { h->refill_wait = atoi(e5); if (h->refill_wait < 0) h->refill_wait = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
+  h->compact_gap = p->lane_compact;
+  if (const char *e9 = getenv("MPC_LANE_COMPACT")) { h->compact_gap = atoi(e9); h->compact_env = true; if (h->compact_gap < 0) h->compact_gap = 0; }
+  if (const char *e6 = getenv("MPC_FINISH_DIV")) { h->finish_div = atoi(e6); if (h->finish_div < 1) h->finish_div = 1; }
+  if (const char *e7 = getenv("MPC_FINISH_REFILL_MIN")) { h->finish_refill_min = atoi(e7); if (h->finish_refill_min < 1) h->finish_refill_min = 1; }
+  if (const char *e8 = getenv("MPC_FINISH_REFILL_WAIT")) { h->finish_refill_wait = atoi(e8); if (h->finish_refill_wait < 0) h->finish_refill_wait = 0; }
   *out = h;
   return MPC_OK;
 }
@@ -909,6 +1022,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   }
   h->params = *p;
   set_cuts(h, p);
+  if (!h->compact_env) h->compact_gap = p->lane_compact;
   return MPC_OK;
 }
 
@@ -1209,10 +1323,12 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.out_inst = h->d_list + 2 * h->io_stride; U.out_src = h->d_list + 3 * h->io_stride; U.out_park = h->d_park + (int64_t)kParkRows * h->io_stride;
   U.src_ws = ws32; U.src_tile_reals = h->ws_stride_f32;
   U.resume = 1; U.promote_in = 1;
-  U.refill_min = h->refill_min; U.refill_wait = h->refill_wait;
+  U.refill_min = h->finish_refill_min; U.refill_wait = h->finish_refill_wait;
+  U.compact_gap = B >= h->compact_min_batch ? h->compact_gap : 0;
+  const unsigned waves2 = (waves + (unsigned)h->finish_div - 1) / (unsigned)h->finish_div;
   /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
   U.tail_cut = tail.tail_cut; U.t_cap = tail.t_cap; U.t_count = tail.t_count; U.t_inst = tail.t_inst; U.t_park = tail.t_park; U.t_iter = tail.t_iter;
-  hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
+  hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves2), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
   MPC_HIP_CHECK(hipGetLastError());
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
@@ -1338,6 +1454,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
     T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    T.compact_gap = (n_cuts == 0 && B >= h->compact_min_batch) ? h->compact_gap : 0;     /* (a phase that parks keeps iterates in its columns) */
     tail_fields(T);
     const bool pooled = h->pool && n_cuts == 0;      /* a parked iterate stays in its column: phases keep their own tiles */
     T.pool_bits = pooled ? h->pool->bits : nullptr; T.pool_base = pooled ? h->pool->base : nullptr;

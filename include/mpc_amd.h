@@ -139,7 +139,14 @@ typedef struct MpcParams {
   int32_t f32_finish;
   int32_t f64_f32_start;
   double mixed_switch_mu;          /* default 2e-5 */
-  double reserved_d[2];
+  /* Lane compaction.  Memory is fetched in 128-byte lines = the 16-byte groups of 8 neighbouring lanes, so a
+   * line is fetched as long as one of its 8 lanes still runs.  With lane_compact = g > 0 a wave whose running lanes are
+   * spread over g more 8-lane groups than they need moves the ones outside its fullest groups into free lanes inside
+   * them (launches of at least 8 192 instances, single-lane arithmetic unchanged: results are bitwise the same).
+   * Default 2; 0 = off. */
+  int32_t lane_compact;
+  int32_t reserved_i;
+  double reserved_d;
 } MpcParams;
 
 typedef struct MpcHandle MpcHandle;

@@ -238,3 +238,59 @@ extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t 
   }
   return MPC_OK;
 }
+
+/* What the device's staged workspace moves per instance: the same solver on a workspace that counts the reals its sweeps
+ * ask for (stage_fetch_* = one LDS-DMA record each, store_run = the group stores) -- the bytes the ACTIVE lanes of a wave
+ * request, to put beside the FETCH_SIZE / WRITE_SIZE counters of a launch (tools/traffic_model.py).  counts[i] = reals
+ * fetched, reals stored, passes (Solver::step calls), iterations. */
+struct TrafficCount { long long fetched = 0, stored = 0; };
+template <class R>
+struct CountingWorkspace : mpc::HostWorkspace<R> {
+  using F = mpc::Fields<R>;
+  TrafficCount *c;
+  CountingWorkspace(R *b, TrafficCount *cc) : mpc::HostWorkspace<R>{b}, c(cc) {}
+  template <int F0, int COUNT> void store_run(int k, int I, const R *v) const {
+    c->stored += (COUNT + F::G - 1) / F::G * F::G;
+    mpc::HostWorkspace<R>::template store_run<F0, COUNT>(k, I, v);
+  }
+  void setD(int k, int j, R v) const { c->stored += 1; mpc::HostWorkspace<R>::setD(k, j, v); }
+  void stage_fetch_it(int, int, int) const { c->fetched += F::IT_SZ; }
+  void stage_fetch_itf(int, int, int) const { c->fetched += 16; }
+  void stage_fetch_d(int, int) const { c->fetched += F::D_N; }
+  void stage_fetch_g(int, int, int) const { c->fetched += F::GAIN_SZ; }
+};
+
+template <class R>
+static int traffic_t(const MpcParams *p, int64_t B, int64_t ld, const R *state, const R *coeffs, const R *yaw_lo, const R *yaw_hi,
+                     const R *weights, int64_t *counts) {
+  if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
+  using WS = CountingWorkspace<R>;
+  using SV = mpc::Solver<WS, R>;
+  std::vector<R> wsbuf((size_t)(p->N - 1) * mpc::Fields<R>::STAGE_SZ);
+  for (int64_t i = 0; i < B; i++) {
+    R st[6], cf[MPC_NCOEF], w[MPC_NW];
+    for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+    for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+    for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)p->weights[q];
+    TrafficCount c;
+    SV S(*p, WS(wsbuf.data(), &c));
+    int s = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0;
+    long long passes = 0;
+    if (s == MPC_STATUS_SUCCESS) {
+      S.begin(true);
+      for (;;) {
+        const int r = S.step();
+        ++passes;
+        if (r == SV::MPC_RUNNING) continue;
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0) { attempt = 1; it_total += S.iters; S.start_point(); S.begin(false); continue; }
+        break;
+      }
+    }
+    counts[4 * i + 0] = c.fetched; counts[4 * i + 1] = c.stored; counts[4 * i + 2] = passes; counts[4 * i + 3] = S.iters + it_total;
+  }
+  return MPC_OK;
+}
+extern "C" int mpc_host_twin_traffic(const MpcParams *p, int64_t B, int64_t ld, const double *state, const double *coeffs,
+                                     const double *yaw_lo, const double *yaw_hi, const double *weights, int64_t *counts) {
+  return traffic_t<double>(p, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, counts);
+}

@@ -474,6 +474,57 @@ def test_multi_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torc
             os.environ["MPC_PASS_CUT"] = old
 
 
+def test_lane_compaction_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """MpcParams.lane_compact (default 2; MPC_LANE_COMPACT in the environment overrides): once a launch's counter is exhausted, a wave moves its running lanes out of sparsely used
+    8-lane groups into free lanes of its fullest groups (solver scalars through LDS, the iterate column to column).  Not a bit
+    may change: plain fp64 (N = 10, ragged batch, and N = 25), the fp64 phase of both mixed-precision modes, per-instance
+    weights, and together with deferred tails."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    old = os.environ.get("MPC_LANE_COMPACT")
+
+    def solve(q, b, w, dt_):
+        B = b["state"].shape[1]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=dt_)
+        with pkg.BatchedMPC(q, B, device=0) as mpc:
+            r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=None if w is None else t(w), want_traj=True)
+            mpc.tail_wait()
+            torch.cuda.synchronize()
+            return {k: v.cpu().numpy() for k, v in r.items()}
+
+    try:
+        cases = []
+        for N, dt, B, sweep, prec, f32s, cut in ((10, 0.1, 16384 + 11, False, pkg.PRECISION_F64, 0, 0), (25, 0.05, 4096, False, pkg.PRECISION_F64, 0, 0),
+                                                 (10, 0.1, 8192, True, pkg.PRECISION_F64, 0, 0), (10, 0.1, 16384, False, pkg.PRECISION_F64, 1, 0),
+                                                 (10, 0.1, 16384, True, pkg.PRECISION_F32, 0, 0), (10, 0.1, 16384, True, pkg.PRECISION_F64, 0, 14)):
+            q = params.copy(); q.N = N; q.dt = dt; q.precision = prec; q.f64_f32_start = f32s; q.tail_cut = cut
+            b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=91)
+            w = pkg.scenarios.weight_sweep(B, q, seed=92) if sweep else None
+            cases.append((q, b, w, torch.float32 if prec == pkg.PRECISION_F32 else torch.float64))
+        res = {}
+        for gap in ("0", "1", "2", "3"):
+            os.environ["MPC_LANE_COMPACT"] = gap
+            res[gap] = [solve(*c) for c in cases]
+        os.environ.pop("MPC_LANE_COMPACT", None)
+        res["param 0"] = []
+        res["param 2"] = []
+        for (q, b, w, dt_) in cases:                       # the same through MpcParams.lane_compact (default 2)
+            assert q.lane_compact == 2
+            res["param 2"].append(solve(q, b, w, dt_))
+            q0 = q.copy(); q0.lane_compact = 0
+            res["param 0"].append(solve(q0, b, w, dt_))
+        for gap in res:
+            for j, (r, r0) in enumerate(zip(res[gap], res["0"])):
+                for key in ("out", "traj", "status", "iters"):
+                    assert np.array_equal(r[key], r0[key]), (gap, j, key)
+        assert all((r["status"] == 0).mean() > 0.99 for r in res["0"])
+    finally:
+        if old is None:
+            os.environ.pop("MPC_LANE_COMPACT", None)
+        else:
+            os.environ["MPC_LANE_COMPACT"] = old
+
+
 def test_tile_pool_is_bitwise_identical_and_used(pkg, golden_dir, waypoints, torch_dev):
     """MPC_TILE_POOL=1: waves take their workspace tile from a per-XCD pool shared by all handles instead of their
     handle's own workspace.  Three handles on three streams, several rounds without a pause in between (so tiles change

@@ -310,5 +310,63 @@ PY
   run default_again
   timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   plain fp64               ', r['value']/1e6)" | tee -a $P
   ;;
+fd)   # the fp64 phase of a mixed solve as a narrower grid whose lanes take the promoted instances in turn
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --f64-f32-start --steps 100 "$@" > $OUT/r03fd_$tag.json 2> $OUT/r03fd_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03fd_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  run div1_i3 --inflight 3
+  for d in 2 3 4 6; do MPC_FINISH_DIV=$d run div${d}_i3 --inflight 3; done
+  for d in 2 4; do MPC_FINISH_DIV=$d MPC_FINISH_REFILL_MIN=8 MPC_FINISH_REFILL_WAIT=4 run div${d}_i3_r8_4 --inflight 3; done
+  for d in 2 4; do MPC_FINISH_DIV=$d MPC_FINISH_REFILL_MIN=1 MPC_FINISH_REFILL_WAIT=0 run div${d}_i3_r1_0 --inflight 3; done
+  for d in 2 4; do MPC_FINISH_DIV=$d run div${d}_i4 --inflight 4; done
+  for d in 2 4; do MPC_FINISH_DIV=$d run div${d}_i2 --inflight 2; done
+  run div1_i3_again --inflight 3
+  timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   plain fp64               ', r['value']/1e6)" | tee -a $P
+  ;;
+lc)   # lane compaction (MPC_LANE_COMPACT=gap): bitwise test, then A/B on the headline, plain and fp32 start
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "lane_compaction" > $OUT/r03lc_pytest.log 2>&1; rc=$?; echo "pytest exit=$rc" | tee -a $P; tail -15 $OUT/r03lc_pytest.log
+  if [ $rc -ne 0 ]; then exit 1; fi
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 "$@" > $OUT/r03lc_$tag.json 2> $OUT/r03lc_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03lc_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for rep in a b; do
+    for g in 0 1 2 3; do MPC_LANE_COMPACT=$g run plain_g${g}_$rep; done
+    for g in 0 1 2 3; do MPC_LANE_COMPACT=$g run f32s_g${g}_$rep --f64-f32-start --inflight 3; done
+  done
+  for g in 0 2; do MPC_LANE_COMPACT=$g run plain_i3_g${g} --inflight 3; done
+  ;;
+lp)   # lane compaction: what the counters say it saves (FETCH_SIZE / WRITE_SIZE / SQ passes with and without)
+  cd /tmp && export TMPDIR=/tmp
+  for g in 0 2; do
+    export MPC_LANE_COMPACT=$g
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/r03lp_g${g}_$c -o pmc -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs > /dev/null 2> $OUT/r03lp_g${g}_$c.err; echo "g=$g $c exit=$?" | tee -a $P
+    done
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/r03lp_g${g}_SQ -o pmc -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs > /dev/null 2> $OUT/r03lp_g${g}_SQ.err; echo "g=$g SQ exit=$?" | tee -a $P
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03lp_g${g}_trace -o trace -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs > /dev/null 2> $OUT/r03lp_g${g}_trace.err; echo "g=$g trace exit=$?" | tee -a $P
+  done
+  unset MPC_LANE_COMPACT
+  cd $R
+  python tools/pmc_mean.py $OUT/r03lp_g0_FETCH_SIZE $OUT/r03lp_g0_WRITE_SIZE $OUT/r03lp_g0_SQ $OUT/r03lp_g2_FETCH_SIZE $OUT/r03lp_g2_WRITE_SIZE $OUT/r03lp_g2_SQ | tee $OUT/r03lp_pmc.jsonl
+  find $OUT -path "*r03lp_g*_trace*" -name "*kernel_stats.csv" | while read f; do echo $f; head -3 "$f" | cut -c1-60,400-; done
+  ;;
+ld)   # lane compaction on every leg of the default bench run, A/B/A/B
+  for rep in a b; do for g in 0 2; do
+    MPC_LANE_COMPACT=$g timeout -k 10 400 python bench.py --no-cpu-baseline > $OUT/r03ld_g${g}_$rep.json 2> $OUT/r03ld_g${g}_$rep.err; echo "g=$g $rep exit=$?" | tee -a $P
+    python tools/show_bench.py $OUT/r03ld_g${g}_$rep.json | tee -a $P
+  done; done
+  ;;
 esac
 echo done | tee -a $P
