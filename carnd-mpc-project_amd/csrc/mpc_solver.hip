@@ -372,10 +372,12 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           const int I = S.cur ? FL::IT1 : FL::IT0;
           WS wsrc = ws;
           wsrc.lane = src;
+          /* (plain loads: the column was written through this CU's own L1 by a lane of this wave, and stage_drain() has waited
+           * for the stores; keeping two stages in flight was measured: no difference) */
           for (int k = 0; k < P.N - 1; ++k) {
             R rec[FL::IT_SZ];
 #pragma unroll
-            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = __hip_atomic_load(&wsrc.it(k, I, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = wsrc.it(k, I, f);
             ws.template store_run<0, FL::IT_SZ>(k, I, rec);
           }
           have = true;

@@ -368,5 +368,27 @@ ld)   # lane compaction on every leg of the default bench run, A/B/A/B
     python tools/show_bench.py $OUT/r03ld_g${g}_$rep.json | tee -a $P
   done; done
   ;;
+le)   # lane compaction: the gap, per workload (the legs of the default run, one process each)
+  leg() { tag=$1; name=$2; timeout -k 10 300 python bench.py --leg $name > $OUT/r03le_$tag.json 2> $OUT/r03le_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03le_$tag.json"))
+    print("   %-34s %8.3f M solves/s  %.3f ms/batch" % ("$tag", r["solves_per_s"] / 1e6, r["ms_per_batch"]))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for rep in a b; do for g in 0 1 2 3 4; do
+    for l in configs_3_share configs_3_share_f32_start unfiltered configs_4_share_pure_fp32; do MPC_LANE_COMPACT=$g leg ${l}_g${g}_$rep $l; done
+  done; done
+  ;;
+lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N = 25 share with and without)
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "lane_compaction" > $OUT/r03lf_pytest.log 2>&1; rc=$?; echo "pytest exit=$rc" | tee -a $P; tail -5 $OUT/r03lf_pytest.log
+  if [ $rc -ne 0 ]; then exit 1; fi
+  for rep in a b c; do for g in 0 2; do
+    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline g=$g $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+  done; done
+  ;;
 esac
 echo done | tee -a $P

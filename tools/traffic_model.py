@@ -5,7 +5,7 @@ The test-only host build of the solver header (tests/host_twin) runs the bench's
 every record the device's sweeps fetch (LDS-DMA) or store; instances are grouped 64 to a wave in launch order and a wave's
 pass p touches the lanes that still run.  Printed: the bytes per solve, the sum over the launch, and what the launch would
 fetch if memory were read in sectors of 32 / 64 / 128 B (2 / 4 / 8 neighbouring lanes of a 16-byte group) or whole rows --
-to be read beside FETCH_SIZE / WRITE_SIZE in profiles/r03_pmc_summary.json.  CPU only (about a minute); writes JSON to stdout."""
+to be read beside FETCH_SIZE / WRITE_SIZE with and without lane compaction (profiles/r03_lane_compact.json).  CPU only (about a minute); writes JSON to stdout."""
 import ctypes as C
 import json
 import os
@@ -59,14 +59,20 @@ def main():
                 act = row > ps
                 tot += act.reshape(-1, lanes).any(1).sum() * lanes * mean_pp
         out["launch_fetch_GB_if_%dB_sectors" % (16 * lanes)] = (tot + io_in * B) / 1e9
+    # the same lanes packed perfectly into the fewest lines at every pass: what any compaction scheme could reach at best
+    tot = 0.0
+    for w in range(W):
+        row = P[w]
+        for ps in range(int(row.max())):
+            tot += -(-int((row > ps).sum()) // 8) * 8 * mean_pp
+    out["launch_fetch_GB_if_128B_lines_perfectly_packed"] = (tot + io_in * B) / 1e9
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
-        out["measured_fetch_GB"] = pm["FETCH_SIZE"] * 2047.97 / 1e9
-        out["measured_write_GB"] = pm["WRITE_SIZE"] * 1024 / 1e9
-        out["measured_over_active_lanes_fetch"] = out["measured_fetch_GB"] / out["launch_fetch_GB_active_lanes"] * (65536 / B)
-        out["measured_over_active_lanes_write"] = out["measured_write_GB"] / out["launch_write_GB_active_lanes"] * (65536 / B)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_lane_compact.json")))["counters_per_launch_headline_fp64_65536"]
+        out["measured_fetch_GB_lane_compact_0_and_2"] = pm["fetched_GB"]
+        out["measured_write_GB_lane_compact_0_and_2"] = pm["written_GB"]
+        out["measured_over_active_lanes_fetch"] = [v / out["launch_fetch_GB_active_lanes"] * (B / 65536) for v in pm["fetched_GB"]]
     except Exception as e:  # noqa: BLE001
-        out["measured"] = "profiles/r03_pmc_summary.json not readable: %s" % e
+        out["measured"] = "profiles/r03_lane_compact.json not readable: %s" % e
     print(json.dumps(out, indent=1))
 
 
