@@ -336,7 +336,8 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
       const int n = n_mv < n_fr ? n_mv : n_fr;
       if (n > 0) {
         ws.stage_drain();                        /* the trial sweep's stores have landed, the staging buffers are idle */
-        double *mb = smem;                       /* [38][64]: Solver::park scalars, instance, passes */
+        static_assert(!STAGING || staging_lds_bytes<R>() >= (size_t)(kParkRows + 2) * 64 * sizeof(double), "the mailbox must fit the staging buffers");
+        double *mb = smem;                       /* [kParkRows + 2][64]: Solver::park scalars, instance, passes */
         const unsigned long long below = (1ull << threadIdx.x) - 1ull;
         const bool is_src = movable && __builtin_popcountll(mv & below) < n;
         const int my_f = __builtin_popcountll(fr & below);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         if (is_src) {
           const unsigned ln = threadIdx.x;
           S.park([mb, ln](int q) -> double & { return mb[q * 64 + ln]; }, attempt, it_total);
-          mb[36 * 64 + ln] = (double)i; mb[37 * 64 + ln] = (double)passes;
+          mb[kParkRows * 64 + ln] = (double)i; mb[(kParkRows + 1) * 64 + ln] = (double)passes;
           have = false;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           unsigned long long m = mv;
           for (int r = 0; r < my_f; ++r) m &= m - 1ull;
           const int src = __builtin_ctzll(m);
-          i = (int64_t)mb[36 * 64 + src]; passes = (int)mb[37 * 64 + src];
+          i = (int64_t)mb[kParkRows * 64 + src]; passes = (int)mb[(kParkRows + 1) * 64 + src];
           R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
           for (int q = 0; q < 6; q++) st[q] = (R)state[q * ld + i];
