@@ -390,5 +390,19 @@ lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N 
     MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
   done; done
   ;;
+us)   # the unfiltered population with deferred tails: run length (the drain of the last tails is inside the clock) and the cut
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --population survey --tail-ring 64 "$@" > $OUT/r03us_$tag.json 2> $OUT/r03us_$tag.err; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r03us_$tag.json"))
+    print("   %-22s %8.3f M solves/s  %.3f ms/batch  status %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], {k: v for k, v in r["status_counts"].items() if v}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+  }
+  for st in 500 1000 2000 4000; do run c20_s$st --tail-cut 20 --steps $st; done
+  for c in 14 16 18 22; do run c${c}_s2000 --tail-cut $c --steps 2000; done
+  run c18_s2000_i3 --tail-cut 18 --steps 2000 --inflight 3
+  ;;
 esac
 echo done | tee -a $P
