@@ -128,7 +128,7 @@ struct MpcPhase {
    * spread over `compact_gap` more 8-lane groups than they need moves the ones outside its fullest groups into free lanes
    * inside them: solver scalars through LDS (the staging buffers are idle between passes), set-up repeated from the inputs,
    * the iterate copied column to column -- the arithmetic of an instance does not depend on its lane. */
-  int32_t compact_gap;
+  int32_t compact_gap, compact_cooldown;   /* (passes without another move after one) */
   /* Tile pool (MpcTilePool, optional): instead of tile number blockIdx of the handle's own workspace a wave takes a free
    * tile from the pool of ITS XCD and gives it back when it leaves, so that the addresses the device cycles through are
    * the tiles of the resident waves and not those of every batch in flight. */
@@ -315,7 +315,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
                                                                                * bounds): the start point is reported at the next hand-over */
           }
         }
-        if (MPC_WAVE_ANY(exhausted)) more = false;   /* the counter only grows: what one lane found empty is empty for all */
+        /* The counter only grows: what one lane found empty is empty for all.  (Until then a finished lane does take again,
+         * also in a launch that has a lane for every instance: with batches in flight the last waves of a grid start late,
+         * and the lanes that finish early in its first waves take their instances -- those waves then find nothing and leave.
+         * Declaring the counter exhausted after every lane's first take was measured: -6 % on the headline.) */
+        if (MPC_WAVE_ANY(exhausted)) more = false;
       } else ++waited;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           have = true;
         }
         __builtin_amdgcn_wave_barrier();
-        cooldown = 2;
+        cooldown = T.compact_cooldown;
       }
     }
 #endif
@@ -788,6 +792,7 @@ struct MpcHandle {
   int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
   int compact_gap = 0;        /* MpcParams.lane_compact, or MPC_LANE_COMPACT in the environment (measurement aid): see MpcPhase.compact_gap */
   bool compact_env = false;
+  int compact_cooldown = 2;   /* MPC_LANE_COMPACT_COOLDOWN */
   int64_t compact_min_batch = 8192;   /* smaller launches are latency-bound: the moves cost more than the lines they save */
   int finish_div = 1;         /* mixed precision: the fp64 phase runs ceil(waves / finish_div) waves whose lanes take the promoted
                                * instances in turn (MPC_FINISH_DIV) */
@@ -995,6 +1000,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
   h->compact_gap = p->lane_compact;
   if (const char *e9 = getenv("MPC_LANE_COMPACT")) { h->compact_gap = atoi(e9); h->compact_env = true; if (h->compact_gap < 0) h->compact_gap = 0; }
+  if (const char *e10 = getenv("MPC_LANE_COMPACT_COOLDOWN")) { h->compact_cooldown = atoi(e10); if (h->compact_cooldown < 0) h->compact_cooldown = 0; }
   if (const char *e6 = getenv("MPC_FINISH_DIV")) { h->finish_div = atoi(e6); if (h->finish_div < 1) h->finish_div = 1; }
   if (const char *e7 = getenv("MPC_FINISH_REFILL_MIN")) { h->finish_refill_min = atoi(e7); if (h->finish_refill_min < 1) h->finish_refill_min = 1; }
   if (const char *e8 = getenv("MPC_FINISH_REFILL_WAIT")) { h->finish_refill_wait = atoi(e8); if (h->finish_refill_wait < 0) h->finish_refill_wait = 0; }
@@ -1328,6 +1334,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.resume = 1; U.promote_in = 1;
   U.refill_min = h->finish_refill_min; U.refill_wait = h->finish_refill_wait;
   U.compact_gap = B >= h->compact_min_batch ? h->compact_gap : 0;
+  U.compact_cooldown = h->compact_cooldown;
   const unsigned waves2 = (waves + (unsigned)h->finish_div - 1) / (unsigned)h->finish_div;
   /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
   U.tail_cut = tail.tail_cut; U.t_cap = tail.t_cap; U.t_count = tail.t_count; U.t_inst = tail.t_inst; U.t_park = tail.t_park; U.t_iter = tail.t_iter;
@@ -1457,6 +1464,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
     T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    T.compact_cooldown = h->compact_cooldown;
     T.compact_gap = (n_cuts == 0 && B >= h->compact_min_batch) ? h->compact_gap : 0;     /* (a phase that parks keeps iterates in its columns) */
     tail_fields(T);
     const bool pooled = h->pool && n_cuts == 0;      /* a parked iterate stays in its column: phases keep their own tiles */

@@ -404,5 +404,37 @@ PY
   for c in 14 16 18 22; do run c${c}_s2000 --tail-cut $c --steps 2000; done
   run c18_s2000_i3 --tail-cut 18 --steps 2000 --inflight 3
   ;;
+lg)   # lane compaction: gap x cooldown (passes without another move), headline and the N = 25 share
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "lane_compaction or multi_phase or deferred_tails_are_bitwise" > $OUT/r03lg_pytest.log 2>&1; rc=$?; echo "pytest exit=$rc" | tee -a $P; tail -5 $OUT/r03lg_pytest.log
+  if [ $rc -ne 0 ]; then exit 1; fi
+  for rep in a b; do for gc in "0 2" "2 2" "2 0" "1 0" "1 1" "3 0"; do
+    set -- $gc
+    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+  done; done
+  ;;
+lh)   # same-box A/B of the builds in gpurun_in/ (libmpc_<tag>.so): headline and the N = 25 share, lane compaction off / on
+  cp carnd-mpc-project_amd/lib/libmpc_amd.so /tmp/libmpc_keep.so
+  for rep in a b c; do for f in gpurun_in/libmpc_*.so; do
+    cp $f carnd-mpc-project_amd/lib/libmpc_amd.so; t=$(basename $f .so)
+    for gc in "0 2" "2 2" "2 0" "1 0"; do
+      set -- $gc
+      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
+      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+    done
+  done; done
+  cp /tmp/libmpc_keep.so carnd-mpc-project_amd/lib/libmpc_amd.so
+  ;;
+li)   # instruction-cache counters of the builds in gpurun_in/ (a 6 % swing of the headline between two builds whose sweeps are identical)
+  cp carnd-mpc-project_amd/lib/libmpc_amd.so /tmp/libmpc_keep.so
+  cd /tmp && export TMPDIR=/tmp
+  for f in $R/gpurun_in/libmpc_*.so; do
+    cp $f $R/carnd-mpc-project_amd/lib/libmpc_amd.so; t=$(basename $f .so)
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/r03li_$t -o pmc -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs > /dev/null 2> $OUT/r03li_$t.err; echo "$t exit=$?" | tee -a $P
+  done
+  cp /tmp/libmpc_keep.so $R/carnd-mpc-project_amd/lib/libmpc_amd.so
+  cd $R
+  for f in gpurun_in/libmpc_*.so; do t=$(basename $f .so); python tools/pmc_mean.py $OUT/r03li_$t | tee -a $P; done
+  ;;
 esac
 echo done | tee -a $P
