@@ -335,12 +335,14 @@ LEGS = {
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
                   dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")),
-    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24, steps=80)),
-    "configs_3_share_f32_start": ("the same share with MpcParams.f64_f32_start = 1 (early iterations on the fp32 record: the long-horizon workspace, 640 KB per wave, "
-                                  "does not fit the Infinity Cache), eight batches in flight",
-                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, steps=80,
-                                       f32_start=True)),
+    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64, as shipped: "
+                        "MpcParams.f64_f32_start = auto runs the early iterations of horizons of 15 steps and more on the fp32 record (the long-horizon "
+                        "workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, steps=80,
+                             f32_start=True)),
+    "configs_3_share_single_phase": ("the same share with f64_f32_start = 0 (every iteration in fp64), deferred tails, four batches in flight",
+                                     dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24,
+                                          steps=80)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
                         "(epsi / v incl. 0 / delta / a)",
                         dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "

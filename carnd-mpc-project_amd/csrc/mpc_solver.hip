@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
                   ws.template store_run<FL::F_D, FL::D_N>(k, 0, zero);
                 }
                 S.promoted();
+                attempt = -1;      /* came in from the fp32 phase: should it fail, it is solved again the way the single-phase solve starts */
               } else {
                 WS wsrc = ws;
                 wsrc.tile = (typename WS::greal *)((const R *)T.src_ws + (int64_t)(src >> 6) * tile_reals);
@@ -409,7 +410,13 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         pk[35 * lp] = r == SV::MPC_PROMOTE ? 0.0 : 1.0;
         have = false; more = false; col_busy = true;     /* the column keeps the parked iterate: this lane takes nothing else */
       } else if (r != SV::MPC_RUNNING) {
-        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        if (attempt < 0 && r != MPC_STATUS_SUCCESS) {
+          /* an instance the fp32 phase started and the fp64 phase could not finish (1 of 8 192 at N = 25: the line search
+           * fails from where fp32 left it): the verdict on it is the single-phase solve's -- from the start point, as that begins */
+          attempt = 0; it_total += S.iters;
+          S.start_point();
+          S.begin(true);
+        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
           attempt = 1; it_total += S.iters;
           S.start_point();
@@ -561,7 +568,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P
     if (have) {
       const int r = S.step();
       if (r != SV::MPC_RUNNING) {
-        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        if (attempt < 0 && r != MPC_STATUS_SUCCESS) {        /* (as in mpc_solve_kernel: started by the fp32 phase, not finished by fp64) */
+          attempt = 0; it_total += S.iters;
+          S.start_point();
+          S.begin(true);
+        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
           attempt = 1; it_total += S.iters;
           S.start_point();
           S.begin(false);
@@ -853,6 +864,13 @@ static void set_cuts(MpcHandle *h, const MpcParams *p) {
   }
 }
 
+/* two phases per solve (fp32 iterations, fp64 finish)?  F32 handles: f32_finish; F64 handles: f64_f32_start = 1, or 2 (auto,
+ * the default) from the horizon at which the workspace of a full device no longer lives in the Infinity Cache */
+static bool wants_mixed(const MpcParams *p) {
+  if (p->precision == MPC_PRECISION_F32) return p->f32_finish != 0;
+  return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && p->N >= MPC_F32_START_AUTO_N);
+}
+
 static int validate_params(const MpcParams *p) {
   if (!p) return MPC_ERR_INVALID;
   if (p->abi_version != MPC_ABI_VERSION) { g_last_error = "MpcParams.abi_version mismatch"; return MPC_ERR_INVALID; }
@@ -867,6 +885,7 @@ static int validate_params(const MpcParams *p) {
   if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
   if (p->tail_cut < 0 || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
+  if (p->f64_f32_start < 0 || p->f64_f32_start > MPC_F32_START_AUTO) { g_last_error = "f64_f32_start must be 0 (off), 1 (on) or 2 (auto)"; return MPC_ERR_INVALID; }
   if (p->lane_compact < 0 || p->lane_compact > 7) { g_last_error = "lane_compact must be 0 (off) .. 7"; return MPC_ERR_INVALID; }
   return MPC_OK;
 }
@@ -936,7 +955,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
   h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true) * 64;
   h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false) * 64;
-  h->mixed = f32 ? p->f32_finish != 0 : p->f64_f32_start != 0;
+  h->mixed = wants_mixed(p);
   /* MPC_MIXED=0/1 overrides the parameter for every handle of the process: how the whole parity suite was run with the fp32
    * start forced on (tools/r03_session.sh p); a measurement aid, not an interface */
   if (const char *e = getenv("MPC_MIXED")) h->mixed = atoi(e) != 0;
@@ -1014,7 +1033,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
   int rc = validate_params(p);
   if (rc != MPC_OK) return rc;
-  if ((p->precision == MPC_PRECISION_F32 ? p->f32_finish != 0 : p->f64_f32_start != 0) != h->mixed && !getenv("MPC_MIXED")) {
+  if (wants_mixed(p) != h->mixed && !getenv("MPC_MIXED")) {
     g_last_error = "f32_finish / f64_f32_start cannot change on a live handle (they decide the workspaces)"; return MPC_ERR_INVALID;
   }
   if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }

@@ -124,6 +124,20 @@ def twin_solve_mixed(twin, params, batch, weights=None, want_traj=True):
     return {"out": out, "traj": traj, "status": status, "iters": iters, "iters_f32": it32}
 
 
+def twin_solve_mixed_f64(twin, params, batch, weights=None, want_traj=True):
+    """An fp64 handle with f64_f32_start in effect, replayed by the test-only host build (float64 in and out)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    st, cf, yl, yh = f(batch["state"]), f(batch["coeffs"]), f(batch["yaw_lo"]), f(batch["yaw_hi"])
+    B = st.shape[1]
+    out = np.zeros((9, B)); traj = np.zeros((2 * params.N, B)) if want_traj else None
+    status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32); it32 = np.zeros(B, dtype=np.int32)
+    w = f(weights) if weights is not None else None
+    rc = twin.mpc_host_twin_solve_mixed_f64(C.byref(params), C.c_int64(B), C.c_int64(B), vp(st), vp(cf), vp(yl), vp(yh), vp(w),
+                                            vp(out), vp(traj), vp(status), vp(iters), vp(it32))
+    assert rc == 0
+    return {"out": out, "traj": traj, "status": status, "iters": iters, "iters_f32": it32}
+
+
 def oracle_solve_batch(cfg, batch, idx, opt=None, weights=None):
     """Oracle MPC::solve for the selected instances -> dict of arrays (out [9,n], traj [2N,n], status, iters)."""
     n = len(idx)

@@ -170,12 +170,14 @@ extern "C" int mpc_host_twin_solve_reparked_f32(const MpcParams *p, int64_t B, i
 }
 
 
-/* Mixed precision across phases, replayed on the host exactly as the device does it (MpcParams.f32_finish): the fp32 solver
- * runs until it returns MPC_PROMOTE, the instance is parked, an fp64 solver unparks it on its own workspace (iterate record
- * converted field by field), re-evaluates the point and finishes.  fp32 in and out.  iters_f32[i]: iterations of the fp32 phase. */
-extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t ld, const float *state, const float *coeffs,
-                                         const float *yaw_lo, const float *yaw_hi, const float *weights, float *out, float *traj,
-                                         int32_t *status, int32_t *iters, int32_t *iters_f32) {
+/* Mixed precision across phases, replayed on the host exactly as the device does it (MpcParams.f32_finish on an F32 handle:
+ * RIO = float; f64_f32_start on an F64 handle: RIO = double): the fp32 solver runs until it returns MPC_PROMOTE, the instance is
+ * parked, an fp64 solver unparks it on its own workspace (iterate record converted field by field), re-evaluates the point and
+ * finishes; an instance the fp64 phase cannot finish from there is solved again from the start point, as the single-phase solve
+ * begins.  iters_f32[i]: iterations of the fp32 phase. */
+template <class RIO>
+static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *state, const RIO *coeffs, const RIO *yaw_lo, const RIO *yaw_hi,
+                         const RIO *weights, RIO *out, RIO *traj, int32_t *status, int32_t *iters, int32_t *iters_f32) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N, M = N - 1;
   using SF = mpc::Solver<mpc::HostWorkspace<float>, float>;
@@ -187,12 +189,12 @@ extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t 
   for (int64_t i = 0; i < B; i++) {
     float st[6], cf[MPC_NCOEF], w[MPC_NW];
     double std_[6], cfd[MPC_NCOEF], wd[MPC_NW], park[SF::PARK_N];
-    for (int q = 0; q < 6; q++) { st[q] = state[q * ld + i]; std_[q] = st[q]; }
-    for (int q = 0; q < MPC_NCOEF; q++) { cf[q] = coeffs[q * ld + i]; cfd[q] = cf[q]; }
-    for (int q = 0; q < MPC_NW; q++) { w[q] = weights ? weights[q * ld + i] : (float)p->weights[q]; wd[q] = weights ? (double)weights[q * ld + i] : p->weights[q]; }
+    for (int q = 0; q < 6; q++) { st[q] = (float)state[q * ld + i]; std_[q] = (double)state[q * ld + i]; }
+    for (int q = 0; q < MPC_NCOEF; q++) { cf[q] = (float)coeffs[q * ld + i]; cfd[q] = (double)coeffs[q * ld + i]; }
+    for (int q = 0; q < MPC_NW; q++) { w[q] = weights ? (float)weights[q * ld + i] : (float)p->weights[q]; wd[q] = weights ? (double)weights[q * ld + i] : p->weights[q]; }
     SF A(*p, mpc::HostWorkspace<float>{wsf.data()});
     SD D(*p, mpc::HostWorkspace<double>{wsd.data()});
-    int s = A.setup(st, cf, yaw_lo[i], yaw_hi[i], w), attempt = 0, it_total = 0;
+    int s = A.setup(st, cf, (float)yaw_lo[i], (float)yaw_hi[i], w), attempt = 0, it_total = 0;
     bool in_double = false;
     if (iters_f32) iters_f32[i] = 0;
     if (s == MPC_STATUS_SUCCESS) {
@@ -210,12 +212,17 @@ extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t 
           for (int k = 0; k < M; k++)
             mpc::convert_iterate_record<float, double>([&](int f) { return A.ws.it(k, Is, f); }, [&](int f, double v) { D.ws.it(k, Id, f) = v; });
           D.promoted();
+          attempt = -1;
           in_double = true;
           continue;
         }
         if (r == MPC_STATUS_NUMERIC && !in_double) {      /* not-a-number in fp32 is not a verdict: fp64 solves it from the start point */
           (void)D.setup(std_, cfd, (double)yaw_lo[i], (double)yaw_hi[i], wd, true);
           D.begin(true); attempt = 0; it_total = 0; in_double = true;
+          continue;
+        }
+        if (in_double && attempt < 0 && r != MPC_STATUS_SUCCESS) {   /* started by fp32, not finished by fp64: the single-phase solve's verdict */
+          attempt = 0; it_total += D.iters; D.start_point(); D.begin(true);
           continue;
         }
         if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
@@ -228,15 +235,25 @@ extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t 
         break;
       }
     }
-    float *o = out + i;
-    float *t = traj ? traj + i : nullptr;
-    struct Ref { float *q; void operator=(double v) { *q = (float)v; } void operator=(float v) { *q = v; } };
+    RIO *o = out + i;
+    RIO *t = traj ? traj + i : nullptr;
+    struct Ref { RIO *q; void operator=(double v) { *q = (RIO)v; } void operator=(float v) { *q = (RIO)v; } };
     if (in_double) D.unpack([o, ld](int q) { return Ref{o + q * ld}; }, [t, ld](int q) { return Ref{t + q * ld}; }, traj != nullptr, (double)yaw_lo[i], (double)yaw_hi[i]);
-    else A.unpack([o, ld](int q) { return Ref{o + q * ld}; }, [t, ld](int q) { return Ref{t + q * ld}; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
+    else A.unpack([o, ld](int q) { return Ref{o + q * ld}; }, [t, ld](int q) { return Ref{t + q * ld}; }, traj != nullptr, (float)yaw_lo[i], (float)yaw_hi[i]);
     status[i] = s;
     if (iters) iters[i] = (in_double ? D.iters : A.iters) + it_total;
   }
   return MPC_OK;
+}
+extern "C" int mpc_host_twin_solve_mixed(const MpcParams *p, int64_t B, int64_t ld, const float *state, const float *coeffs,
+                                         const float *yaw_lo, const float *yaw_hi, const float *weights, float *out, float *traj,
+                                         int32_t *status, int32_t *iters, int32_t *iters_f32) {
+  return solve_mixed_t<float>(p, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, iters_f32);
+}
+extern "C" int mpc_host_twin_solve_mixed_f64(const MpcParams *p, int64_t B, int64_t ld, const double *state, const double *coeffs,
+                                             const double *yaw_lo, const double *yaw_hi, const double *weights, double *out, double *traj,
+                                             int32_t *status, int32_t *iters, int32_t *iters_f32) {
+  return solve_mixed_t<double>(p, B, ld, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, iters_f32);
 }
 
 /* What the device's staged workspace moves per instance: the same solver on a workspace that counts the reals its sweeps

@@ -15,7 +15,8 @@ import pytest
 
 import oracle_lib as O
 from helpers import (F32_TOL_ACCEL, F32_TOL_COST_REL, F32_TOL_STATE, F32_TOL_STEER, F32_TOL_TRAJ, F32PURE_TOL_ACCEL, F32PURE_TOL_COST_REL,
-                     F32PURE_TOL_STATE, F32PURE_TOL_STEER, F32PURE_TOL_TRAJ, f32_forks, oracle_solve_batch, twin_solve, twin_solve_f32, twin_solve_mixed, vp)
+                     F32PURE_TOL_STATE, F32PURE_TOL_STEER, F32PURE_TOL_TRAJ, f32_forks, oracle_solve_batch, twin_solve, twin_solve_f32, twin_solve_mixed,
+                     twin_solve_mixed_f64, vp)
 
 ZERO_V = (0.0, 1.0, 100.0)      # the velocity weights of SURVEY.md 8d Config 5 (submission-report.md:315: "the vehicle decelerates")
 
@@ -90,6 +91,26 @@ def test_f32_finish_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, 
     _check_f32(r, r64, "mixed vs twin64 (N=%d)" % N, B)
     assert abs(r["iters"].mean() - r64["iters"].mean()) < 1.0
     assert r["iters_f32"].mean() > 0.55 * r["iters"].mean()                          # most of the iterations run in fp32
+
+
+def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, host_twin, golden_dir, waypoints):
+    """MpcParams.f64_f32_start = MPC_F32_START_AUTO (the default): fp64 handles with N >= 15 run their early iterations on the fp32
+    record.  The whole N = 25 batch of the full-size soak (8 192 instances) through the host replay of the two phases: same status
+    as the single-phase solve on every instance, outputs within the fp64 tolerances -- including the instances the fp64 phase
+    cannot finish from where fp32 left them (a failed line search on the device before this rule existed): those are solved again
+    from the start point the way the single-phase solve begins, and take its verdict."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
+    assert params.f64_f32_start == 2 and params.N >= 15
+    B = 8192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=103)
+    r = twin_solve_mixed_f64(host_twin, params, b)
+    r0 = twin_solve(host_twin, params, b)
+    assert np.array_equal(r["status"], r0["status"]) and (r["status"] == 0).all()
+    d = np.abs(r["out"][:8] - r0["out"][:8])
+    assert d[6].max() <= 1e-6 and d[7].max() <= 1e-6 and d[:6].max() <= 1e-5 and np.abs(r["traj"] - r0["traj"]).max() <= 1e-5
+    again = np.nonzero(r["iters"] > r0["iters"] + r["iters_f32"] - 5)[0]        # fp32 phase + fp64 attempt + the whole single-phase solve
+    assert 1 <= len(again) <= 8 and (r["iters_f32"] > 0).all()
+    assert abs(r["iters"].mean() - r0["iters"].mean()) < 0.5
 
 
 def test_f32_pure_twin_weight_sweep_matches_fp64_oracle(pkg, host_twin, golden_dir, waypoints):

@@ -373,7 +373,7 @@ def test_staged_and_plain_kernels_are_bitwise_identical(pkg, golden_dir, waypoin
     old = os.environ.get("MPC_STAGING")
     try:
         for N, dt, B in ((10, 0.1, 12288 + 37), (25, 0.05, 2048)):
-            q = params.copy(); q.N = N; q.dt = dt
+            q = params.copy(); q.N = N; q.dt = dt; q.f64_f32_start = 0     # variants of the single-phase kernel
             b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=77)
             for stg in ("1", "0"):
                 os.environ["MPC_STAGING"] = stg
@@ -400,7 +400,7 @@ def test_lds_resident_kernel_is_bitwise_identical(pkg, golden_dir, waypoints, to
         for N, dt, B in ((10, 0.1, 1), (10, 0.1, 2000 + 13), (25, 0.05, 777), (40, 0.025, 130)):
             for prec in (pkg.PRECISION_F64, pkg.PRECISION_F32):
                 q = params.copy(); q.N = N; q.dt = dt; q.precision = prec
-                q.f32_finish = 0                       # the LDS-resident kernel is a variant of the single-phase solve
+                q.f32_finish = 0; q.f64_f32_start = 0  # the LDS-resident kernel is a variant of the single-phase solve
                 b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=79)
                 tdt = torch.float32 if prec == pkg.PRECISION_F32 else torch.float64
                 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=tdt)
@@ -432,7 +432,7 @@ def test_multi_phase_solve_is_bitwise_identical(pkg, golden_dir, waypoints, torc
     old = os.environ.get("MPC_PASS_CUT")
     try:
         for N, dt, B in ((10, 0.1, 16384 + 11), (25, 0.05, 8192)):
-            q = params.copy(); q.N = N; q.dt = dt
+            q = params.copy(); q.N = N; q.dt = dt; q.f64_f32_start = 0     # cut schedules re-pack the single-phase solve
             b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=78)
             res = {}
             for cut in ("0", "12", "5", "4,4,4,4", "3,9", "16,16,32"):
@@ -611,16 +611,18 @@ def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N,
     assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "N=%d" % N)
 
 
-@pytest.mark.parametrize("case", ["headline", "weights", "f32", "mixed", "N25"])
+@pytest.mark.parametrize("case", ["headline", "weights", "f32", "mixed", "N25", "N25plain"])
 def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_dev, case):
     """MpcParams.tail_cut: instances still running after `tail_cut` passes leave their launch (status PENDING at the bulk's
     completion) and are finished by the handle's tail launches; after mpc_tail_wait every array is bitwise what the single
     launch writes.  Also with the queue slots recycled many times (ring of 2), with a queue too small for the batch
     (the rest finishes in its launch), and with several batches outstanding."""
     import torch
-    over = dict(N=25, dt=0.05) if case == "N25" else {}
-    cfgname = "config-stable.json" if case == "N25" else "config-fast.json"
+    over = dict(N=25, dt=0.05) if case.startswith("N25") else {}
+    cfgname = "config-stable.json" if case.startswith("N25") else "config-fast.json"
     params = pkg.params_from_json(os.path.join(golden_dir, cfgname), **over)
+    if case == "N25plain":
+        params.f64_f32_start = 0                              # "N25" itself runs as shipped: long horizons start on the fp32 record
     f32 = case in ("f32", "mixed")
     if f32:
         params.precision = pkg.PRECISION_F32

@@ -379,7 +379,7 @@ except Exception as e:
 PY
   }
   for rep in a b; do for g in 0 1 2 3 4; do
-    for l in configs_3_share configs_3_share_f32_start unfiltered configs_4_share_pure_fp32; do MPC_LANE_COMPACT=$g leg ${l}_g${g}_$rep $l; done
+    for l in configs_3_share_single_phase configs_3_share unfiltered configs_4_share_pure_fp32; do MPC_LANE_COMPACT=$g leg ${l}_g${g}_$rep $l; done
   done; done
   ;;
 lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N = 25 share with and without)
@@ -387,7 +387,7 @@ lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N 
   if [ $rc -ne 0 ]; then exit 1; fi
   for rep in a b c; do for g in 0 2; do
     MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline g=$g $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share_single_phase g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
   done; done
   ;;
 us)   # the unfiltered population with deferred tails: run length (the drain of the last tails is inside the clock) and the cut
@@ -410,7 +410,7 @@ lg)   # lane compaction: gap x cooldown (passes without another move), headline 
   for rep in a b; do for gc in "0 2" "2 2" "2 0" "1 0" "1 1" "3 0"; do
     set -- $gc
     MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share_single_phase gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
   done; done
   ;;
 lh)   # same-box A/B of the builds in gpurun_in/ (libmpc_<tag>.so): headline and the N = 25 share, lane compaction off / on
@@ -420,7 +420,7 @@ lh)   # same-box A/B of the builds in gpurun_in/ (libmpc_<tag>.so): headline and
     for gc in "0 2" "2 2" "2 0" "1 0"; do
       set -- $gc
       MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t configs_3_share_single_phase gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
     done
   done; done
   cp /tmp/libmpc_keep.so carnd-mpc-project_amd/lib/libmpc_amd.so
@@ -435,6 +435,22 @@ li)   # instruction-cache counters of the builds in gpurun_in/ (a 6 % swing of t
   cp /tmp/libmpc_keep.so $R/carnd-mpc-project_amd/lib/libmpc_amd.so
   cd $R
   for f in gpurun_in/libmpc_*.so; do t=$(basename $f .so); python tools/pmc_mean.py $OUT/r03li_$t | tee -a $P; done
+  ;;
+ip)   # fewer waves than instances / 64 (MPC_INSTANCES_PER_LANE): lanes take instances in turn from the start
+  for rep in a b; do for ipl in 1 2 3; do for nfl in 2 3; do
+    MPC_INSTANCES_PER_LANE=$ipl timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 --inflight $nfl 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline per_lane=$ipl inflight=$nfl $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
+  done; done; done
+  for ipl in 1 2; do for rm in "16 8" "8 4" "32 12"; do set -- $rm
+    MPC_INSTANCES_PER_LANE=$ipl MPC_REFILL_MIN=$1 MPC_REFILL_WAIT=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline per_lane=$ipl refill_min=$1 wait=$2  %.3f M' % (r['value']/1e6))" | tee -a $P
+  done; done
+  ;;
+nx)   # where does the fp32 start begin to pay?  horizon sweep at a constant horizon time of 1.25 s, 32 768 instances
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --config config-stable.json --batch 32768 --steps 60 "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-28s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  for N in 10 12 15 20 25 40; do
+    dt=$(python -c "print(1.25 / $N)")
+    for nfl in 2 4; do run N${N}_plain_i$nfl --N $N --dt $dt --inflight $nfl; done
+    for nfl in 3 8; do run N${N}_f32start_i$nfl --N $N --dt $dt --inflight $nfl --f64-f32-start; done
+  done
   ;;
 esac
 echo done | tee -a $P
