@@ -338,14 +338,17 @@ LEGS = {
     "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64, as shipped: "
                         "MpcParams.f64_f32_start = auto runs the early iterations of horizons of 15 steps and more on the fp32 record (the long-horizon "
                         "workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, steps=80,
-                             f32_start=True)),
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, tail_cut=12, steps=600,
+                             f32_start=True,
+                             note="an instance the fp64 phase cannot finish from the fp32 iterate (1-3 in 8 192) is solved again as the single-phase solve does it: "
+                                  "a chain of 134 iterations here, which deferred tails (tail_cut 12) take out of the launches; without them 7.0-7.3 M, and the "
+                                  "drain of the last tails is inside the clock: 7.2 / 9.3 / 9.7 M solves/s over 80 / 400 / 1000 batches")),
     "configs_3_share_single_phase": ("the same share with f64_f32_start = 0 (every iteration in fp64), deferred tails, four batches in flight",
                                      dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24,
                                           steps=80)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
                         "(epsi / v incl. 0 / delta / a)",
-                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, steps=60, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
                                   "(tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")),
     "configs_4_share_pure_fp32": ("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), deferred tails",
                                   dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=24, steps=150,

@@ -1377,6 +1377,7 @@ struct Solver {
    * point in fp64 and carries on with the same state machine to tol and the polish. */
   static constexpr bool kCanPromote = sizeof(R) == 4;   /* only the fp32 solver ever hands over: none of it is in the fp64 kernels */
   R promote_mu = R(0.0);
+  int promote_cap = kPromoteIterCap;
   bool keep_theta = false;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   R out_prev;     /* the same of the step before (fp32 wants two quiet steps in a row) */
@@ -1492,7 +1493,7 @@ struct Solver {
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
         /* as far as this precision is asked to go -- or an instance that is taking long: the stragglers (steps of a few per
          * cent against a bound for dozens of iterations) are where the noise of fp32 steps costs most; they go on in fp64 */
-        if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= kPromoteIterCap)) return MPC_PROMOTE;
+        if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= promote_cap)) return MPC_PROMOTE;
         if (E0 <= tol) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so

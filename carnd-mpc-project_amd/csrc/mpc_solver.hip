@@ -411,8 +411,12 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         have = false; more = false; col_busy = true;     /* the column keeps the parked iterate: this lane takes nothing else */
       } else if (r != SV::MPC_RUNNING) {
         if (attempt < 0 && r != MPC_STATUS_SUCCESS) {
-          /* an instance the fp32 phase started and the fp64 phase could not finish (1 of 8 192 at N = 25: the line search
-           * fails from where fp32 left it): the verdict on it is the single-phase solve's -- from the start point, as that begins */
+          /* An instance the fp32 phase started (attempt -1) and the fp64 phase could not finish (1-3 of 8 192 at N = 25: the
+           * line search fails from where fp32 left it): it is solved again from the start point exactly as the single-phase
+           * solve does it -- first attempt, then the restart if that fails -- so status AND returned point are that solve's
+           * (the named hard instances of tests/helpers.py stay what the oracle says).  Trying the restart first is cheaper
+           * for these stragglers (their chain: fp32 + the failed fp64 continuation + a whole solve) but was measured to return
+           * the restart's local minimum, or its last iterate, where the single-phase solve returns the first attempt's. */
           attempt = 0; it_total += S.iters;
           S.start_point();
           S.begin(true);

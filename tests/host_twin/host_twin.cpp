@@ -199,6 +199,7 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
     if (iters_f32) iters_f32[i] = 0;
     if (s == MPC_STATUS_SUCCESS) {
       A.promote_mu = (float)p->mixed_switch_mu;
+      if (const char *e = getenv("MPC_TWIN_PROMOTE_CAP")) A.promote_cap = atoi(e);     /* (analysis aid) */
       A.begin(true);
       for (;;) {
         const int r = in_double ? D.step() : A.step();
@@ -221,7 +222,7 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
           D.begin(true); attempt = 0; it_total = 0; in_double = true;
           continue;
         }
-        if (in_double && attempt < 0 && r != MPC_STATUS_SUCCESS) {   /* started by fp32, not finished by fp64: the single-phase solve's verdict */
+        if (in_double && attempt < 0 && r != MPC_STATUS_SUCCESS) {   /* started by fp32, not finished by fp64: solved again as the single-phase solve does it */
           attempt = 0; it_total += D.iters; D.start_point(); D.begin(true);
           continue;
         }

@@ -98,7 +98,7 @@ def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, 
     record.  The whole N = 25 batch of the full-size soak (8 192 instances) through the host replay of the two phases: same status
     as the single-phase solve on every instance, outputs within the fp64 tolerances -- including the instances the fp64 phase
     cannot finish from where fp32 left them (a failed line search on the device before this rule existed): those are solved again
-    from the start point the way the single-phase solve begins, and take its verdict."""
+    from the start point exactly as the single-phase solve does it, and so return its status and its point."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
     assert params.f64_f32_start == 2 and params.N >= 15
     B = 8192
@@ -108,9 +108,9 @@ def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, 
     assert np.array_equal(r["status"], r0["status"]) and (r["status"] == 0).all()
     d = np.abs(r["out"][:8] - r0["out"][:8])
     assert d[6].max() <= 1e-6 and d[7].max() <= 1e-6 and d[:6].max() <= 1e-5 and np.abs(r["traj"] - r0["traj"]).max() <= 1e-5
-    again = np.nonzero(r["iters"] > r0["iters"] + r["iters_f32"] - 5)[0]        # fp32 phase + fp64 attempt + the whole single-phase solve
-    assert 1 <= len(again) <= 8 and (r["iters_f32"] > 0).all()
-    assert abs(r["iters"].mean() - r0["iters"].mean()) < 0.5
+    again = np.nonzero(r["iters"] - r["iters_f32"] > 40)[0]     # the fp64 phase did not just finish them: restarts from the start point
+    assert 1 <= len(again) <= 8 and (r["iters_f32"] > 0).all(), (again, r["iters"][again], r0["iters"][again])
+    assert abs(r["iters"].mean() - r0["iters"].mean()) < 0.5 and r["iters"].max() <= r0["iters"].max() + 60
 
 
 def test_f32_pure_twin_weight_sweep_matches_fp64_oracle(pkg, host_twin, golden_dir, waypoints):

@@ -452,5 +452,18 @@ nx)   # where does the fp32 start begin to pay?  horizon sweep at a constant hor
     for nfl in 3 8; do run N${N}_f32start_i$nfl --N $N --dt $dt --inflight $nfl --f64-f32-start; done
   done
   ;;
+mt)   # mixed-precision legs with deferred tails (an instance the fp64 phase cannot finish is solved again: a long chain)
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  N25="--config config-stable.json --N 25 --dt 0.05 --batch 32768 --steps 80 --f64-f32-start"
+  for c in 0 12 16 24 32; do for nfl in 4 8; do run n25_f32s_c${c}_i$nfl $N25 --inflight $nfl --tail-cut $c; done; done
+  W="--weights-sweep --precision f32 --no-traj --batch 131072 --steps 60"
+  for c in 0 12 16 24 32; do for nfl in 4 8; do run w32_mixed_c${c}_i$nfl $W --inflight $nfl --tail-cut $c; done; done
+  ;;
+mu)   # the N = 25 share as shipped (fp32 start) with deferred tails: run length
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  N25="--config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8"
+  for st in 80 400 1000; do for c in 12 16 20; do run n25_f32s_c${c}_s$st $N25 --steps $st --tail-cut $c --tail-ring 64; done; done
+  run n25_f32s_c0_s400 $N25 --steps 400
+  ;;
 esac
 echo done | tee -a $P
