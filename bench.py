@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64", help="f32 = MPC_PRECISION_F32 (BASELINE.json configs[4])")
     ap.add_argument("--f32-pure", action="store_true", help="--precision f32 with MpcParams.f32_finish = 0: the pure fp32 solver of round 2 "
                     "(tol_f32, looser tolerances) instead of fp32 iterations finished in fp64")
+    ap.add_argument("--f32-phase-refill", action="store_true", help="MpcParams.f32_phase_refill = 1 (mixed precision on heavy-tailed workloads)")
     ap.add_argument("--f64-f32-start", action="store_true", help="fp64 handle with MpcParams.f64_f32_start = 1: the early iterations on the fp32 "
                     "record, every instance finished by the fp64 solver (experimental)")
     ap.add_argument("--switch-mu", type=float, default=0.0, help="MpcParams.mixed_switch_mu (default 2e-5)")
@@ -348,7 +349,7 @@ LEGS = {
                                           steps=80)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
                         "(epsi / v incl. 0 / delta / a)",
-                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, note="MPC_PRECISION_F32 as shipped: fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, f32_refill=True, note="MPC_PRECISION_F32 as shipped, with the two switches for heavy-tailed workloads (tail_cut 12, f32_phase_refill: 18 -> 22 M solves/s): fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
                                   "(tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")),
     "configs_4_share_pure_fp32": ("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), deferred tails",
                                   dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=24, steps=150,
@@ -357,10 +358,11 @@ LEGS = {
 
 
 def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered",
-            velocity_weights=(0.0, 1.0, 100.0), note=None, tail_cut=0, steps=None, f32_pure=False, f32_start=False, hw_queues=8):
+            velocity_weights=(0.0, 1.0, 100.0), note=None, tail_cut=0, steps=None, f32_pure=False, f32_start=False, f32_refill=False, hw_queues=8):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
     params = pkg.params_from_json(os.path.join(golden, config), **over)
     params.f64_f32_start = 1 if f32_start else 0
+    params.f32_phase_refill = 1 if f32_refill else 0
     if f32:
         params.precision = pkg.PRECISION_F32
         params.f32_finish = 0 if f32_pure else 1
@@ -503,6 +505,7 @@ def main():
         params.precision = pkg.PRECISION_F32
         params.f32_finish = 0 if args.f32_pure else 1
     params.f64_f32_start = 1 if args.f64_f32_start else 0
+    params.f32_phase_refill = 1 if args.f32_phase_refill else 0
     if args.switch_mu > 0:
         params.mixed_switch_mu = args.switch_mu
     if args.tol_f32 > 0:

@@ -42,7 +42,7 @@ class MpcParams(C.Structure):
         ("pass_cut_next", C.c_int32 * 3), ("honor_original_bounds", C.c_int32), ("bound_relax_factor", C.c_double),
         ("tail_cut", C.c_int32), ("tail_ring", C.c_int32), ("tail_capacity", C.c_int64),
         ("f32_finish", C.c_int32), ("f64_f32_start", C.c_int32), ("mixed_switch_mu", C.c_double),
-        ("lane_compact", C.c_int32), ("reserved_i", C.c_int32), ("reserved_d", C.c_double),
+        ("lane_compact", C.c_int32), ("f32_phase_refill", C.c_int32), ("reserved_d", C.c_double),
     ]
 
     def copy(self):

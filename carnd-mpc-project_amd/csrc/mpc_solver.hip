@@ -57,6 +57,7 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
 constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
 constexpr int kCounterInts = 16;    /* two counters per phase */
 constexpr int kParkRows = 36;       /* Solver::PARK_N */
+constexpr int kFinPromote = -2, kFinScratch = -3;   /* a lane that waits to hand its instance to the fp64 phase (promoted / to be solved from scratch) */
 constexpr int kTailMaxRing = 64;    /* deferred tails: batches whose stragglers may be outstanding at once */
 constexpr int kTailPerLaunch = 16;  /* queue slots one tail launch serves (they travel as kernel arguments) */
 constexpr int kTailMaxStreams = 4;  /* tail launches that may run side by side */
@@ -117,11 +118,17 @@ struct MpcPhase {
    * floats), is converted field by field, the point is re-evaluated in fp64 and the solve goes on to tol and the polish. */
   int32_t promote_out, promote_in;
   int64_t src_tile_reals;
+  /* The promoted iterates travel in a buffer of their own, [list position / 64][N-1][IT_SZ][64] reals of the fp32 record:
+   * a lane that has handed its instance over is free at once -- it takes the next instance while the launch has any, and
+   * its column is there for lane compaction -- and the fp64 phase reads 64 consecutive entries per wave instead of 64
+   * columns scattered over the fp32 workspace.  (nullptr: the iterate stays in its column, as in a cut schedule.) */
+  void *p_iter;
   /* Hand-over policy.  Writing a finished instance out and fetching the next one (set-up, start point: 270 stores) is
    * divergent code that the whole wave pays for, ~4 us per event against ~80 us per pass, and with 64 lanes finishing at
    * different times nearly every pass would have one.  So finished lanes WAIT until `refill_min` lanes of the wave are
    * waiting, or `refill_wait` passes have gone by, or nothing else is running; then all of them are served at once. */
   int32_t refill_min, refill_wait;
+  int32_t refill_floor;     /* no further takes once fewer lanes than this are running (0 = take whenever there is work) */
   /* Lane compaction (MPC_LANE_COMPACT=gap, measurement aid).  Memory is fetched in 128-byte lines = the 16-byte groups of 8
    * neighbouring lanes, so a line is fetched as long as ONE of its 8 lanes still runs (tools/traffic_model.py: the launch
    * fetches 1.24 x what its running lanes ask for).  Once the launch's counter is exhausted, a wave whose running lanes are
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
   bool queue_full = false;                       /* deferred tails: the batch's queue slot has no room left */
   bool col_busy = false;                         /* this lane's column holds a parked iterate */
-  int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0, cooldown = 0;
+  int attempt = 0, it_total = 0, passes = 0, fin_status = 0, waited = 0, cooldown = 0, passes_wave = 0;
   const int64_t n_work = T.resume ? (int64_t)*T.n_in : B;
   (void)col_busy; (void)cooldown;
   for (;;) {
@@ -243,6 +250,30 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     if (n_wait > 0) {
       if (!MPC_WAVE_ANY(have) || n_wait >= T.refill_min || waited >= T.refill_wait || want_compact) {
         waited = 0;
+        if (fin && fin_status <= kFinPromote) {
+          /* mixed precision, promoted iterates in their own buffer: the hand-over to the next phase happens here, for all the
+           * lanes of the wave that are waiting for it at once (done lane by lane as they promote it cost 20 % of the rate) */
+          const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
+          T.out_inst[pos] = (int32_t)i;
+          T.out_src[pos] = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+          double *pk = T.out_park + pos;
+          const int64_t lp = T.ld_park;
+          S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
+          pk[35 * lp] = fin_status == kFinPromote ? 0.0 : 1.0;
+          if (fin_status == kFinPromote) {
+            ws.stage_drain();                          /* the trial sweep's stores of this wave have landed */
+            const int I = S.cur ? FL::IT1 : FL::IT0, M = P.N - 1;
+            R *dst = (R *)T.p_iter + (pos >> 6) * (int64_t)M * FL::IT_SZ * 64 + (pos & 63);
+            for (int k = 0; k < M; ++k) {
+              R rec[FL::IT_SZ];
+#pragma unroll
+              for (int f = 0; f < FL::IT_SZ; f++) rec[f] = ws.it(k, I, f);
+#pragma unroll
+              for (int f = 0; f < FL::IT_SZ; f++) dst[(k * FL::IT_SZ + f) * 64] = rec[f];
+            }
+          }
+          fin = false;
+        }
         if (fin) {
           RIO *o = out + i;
           RIO *t = traj ? traj + i : nullptr;
@@ -253,6 +284,9 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           if (iters) iters[i] = S.iters + it_total;
           fin = false;
         }
+        /* a wave most of whose lanes have finished starts nothing new: what it would take runs denser in a wave that starts
+         * fresh (the grid has a lane for every instance), and this one would last twice as long for a handful of lanes */
+        if (T.refill_floor > 0 && passes_wave > 0 && MPC_WAVE_COUNT(have) < T.refill_floor) more = false;
         bool exhausted = false;
         if (!have && more) {
           const int64_t pos = (int64_t)atomicAdd(T.take, 1);
@@ -289,9 +323,10 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
                 wsrc.tile = (typename mpc::TiledWorkspace<false, RSRC>::greal *)((const RSRC *)T.src_ws + (int64_t)(src >> 6) * T.src_tile_reals);
                 wsrc.lane = src & 63; wsrc.lbuf = nullptr;
                 const int Is = S.cur ? FS::IT1 : FS::IT0;
+                const RSRC *pit = T.p_iter ? (const RSRC *)T.p_iter + (pos >> 6) * (int64_t)(P.N - 1) * FS::IT_SZ * 64 + (pos & 63) : nullptr;
                 for (int k = 0; k < P.N - 1; ++k) {
                   R rec[FL::IT_SZ] = {};
-                  mpc::convert_iterate_record<RSRC, R>([&](int f) { return (RSRC)wsrc.it(k, Is, f); }, [&](int f, R v) { rec[f] = v; });
+                  mpc::convert_iterate_record<RSRC, R>([&](int f) { return pit ? pit[(k * FS::IT_SZ + f) * 64] : (RSRC)wsrc.it(k, Is, f); }, [&](int f, R v) { rec[f] = v; });
                   ws.template store_run<0, FL::IT_SZ>(k, I, rec);
                   /* the re-evaluation is a trial sweep with step length 0: it multiplies whatever the direction record holds */
                   const R zero[FL::D_N] = {};
@@ -394,11 +429,15 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     }
 #endif
     if (!MPC_WAVE_ANY(have || more || fin)) break;
+    ++passes_wave;
     if (have) {
       const int r = S.step();
       ++passes;
-      if (r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) {
-        /* mixed precision: this phase has taken the instance as far as it is asked to; the next phase's solver takes over.
+      if ((r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) && T.p_iter) {
+        /* mixed precision: this phase has taken the instance as far as it is asked to; it waits for the wave's next hand-over */
+        fin = true; fin_status = r == SV::MPC_PROMOTE ? kFinPromote : kFinScratch; have = false;
+      } else if (r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) {
+        /* the same with the iterate left in its column (MPC_PROMOTE_BUFFER=0): the next phase's solver takes over.
          * Not-a-number in the fp32 phase (states far from the origin late in a closed loop: x^4 terms, lost digits) is not a
          * verdict on the instance: the fp64 solver gets it from the start point (row 35 of the parked scalars says so). */
         const int64_t pos = (int64_t)atomicAdd(T.n_out, 1);
@@ -805,6 +844,7 @@ struct MpcHandle {
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
   int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
+  int refill_floor = 0, refill_floor_f32 = 0;   /* MPC_REFILL_FLOOR / MPC_REFILL_FLOOR_F32 (the fp32 phase of a mixed solve) */
   int compact_gap = 0;        /* MpcParams.lane_compact, or MPC_LANE_COMPACT in the environment (measurement aid): see MpcPhase.compact_gap */
   bool compact_env = false;
   int compact_cooldown = 2;   /* MPC_LANE_COMPACT_COOLDOWN */
@@ -818,6 +858,8 @@ struct MpcHandle {
   int64_t two_phase_min = 8192;
   void *ws2 = nullptr;
   double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
+  void *d_piter = nullptr;    /* mixed precision: the promoted iterates, [io_stride / 64][N-1][IT_SZ of the fp32 record][64] floats */
+  bool promote_buffer = false, promote_env = false;   /* MpcParams.f32_phase_refill (MPC_PROMOTE_BUFFER in the environment overrides: measurement aid) */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
   /* deferred tails (MpcParams.tail_cut > 0; allocated on first use) */
@@ -1024,6 +1066,10 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   h->compact_gap = p->lane_compact;
   if (const char *e9 = getenv("MPC_LANE_COMPACT")) { h->compact_gap = atoi(e9); h->compact_env = true; if (h->compact_gap < 0) h->compact_gap = 0; }
   if (const char *e10 = getenv("MPC_LANE_COMPACT_COOLDOWN")) { h->compact_cooldown = atoi(e10); if (h->compact_cooldown < 0) h->compact_cooldown = 0; }
+  h->promote_buffer = p->f32_phase_refill != 0;
+  if (const char *e11 = getenv("MPC_PROMOTE_BUFFER")) { h->promote_buffer = atoi(e11) != 0; h->promote_env = true; }
+  if (const char *e12 = getenv("MPC_REFILL_FLOOR")) h->refill_floor = atoi(e12);
+  if (const char *e13 = getenv("MPC_REFILL_FLOOR_F32")) h->refill_floor_f32 = atoi(e13);
   if (const char *e6 = getenv("MPC_FINISH_DIV")) { h->finish_div = atoi(e6); if (h->finish_div < 1) h->finish_div = 1; }
   if (const char *e7 = getenv("MPC_FINISH_REFILL_MIN")) { h->finish_refill_min = atoi(e7); if (h->finish_refill_min < 1) h->finish_refill_min = 1; }
   if (const char *e8 = getenv("MPC_FINISH_REFILL_WAIT")) { h->finish_refill_wait = atoi(e8); if (h->finish_refill_wait < 0) h->finish_refill_wait = 0; }
@@ -1055,6 +1101,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   h->params = *p;
   set_cuts(h, p);
   if (!h->compact_env) h->compact_gap = p->lane_compact;
+  if (!h->promote_env) h->promote_buffer = p->f32_phase_refill != 0;
   return MPC_OK;
 }
 
@@ -1077,6 +1124,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   pool_release(h->pool);
   if (h->d_park) (void)hipFree(h->d_park);
   if (h->d_list) (void)hipFree(h->d_list);
+  if (h->d_piter) (void)hipFree(h->d_piter);
   if (h->d_tel) (void)hipFree(h->d_tel);
   for (int q = 0; q < kTailMaxStreams; q++) if (h->tail_stream[q]) (void)hipStreamSynchronize(h->tail_stream[q]);
   for (void *q : {(void *)h->d_tcount, (void *)h->d_tinst, (void *)h->d_ttake, (void *)h->d_tpark, h->d_titer, h->tail_ws})
@@ -1333,6 +1381,8 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   }
   if (!h->d_park) MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
   if (!h->d_list) MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
+  if (!h->d_piter && h->promote_buffer)
+    MPC_HIP_CHECK(hipMalloc(&h->d_piter, sizeof(float) * (size_t)h->io_stride * (size_t)(h->params.N - 1) * mpc::Fields<float>::IT_SZ));
   float *ws32 = sizeof(RIO) == 4 ? (float *)h->ws : (float *)h->ws2;
   double *ws64 = sizeof(RIO) == 4 ? (double *)h->ws2 : (double *)h->ws;
   int32_t *it_out = iters ? iters : h->d_iters;
@@ -1345,6 +1395,9 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   T.out_inst = h->d_list; T.out_src = h->d_list + h->io_stride; T.out_park = h->d_park; T.ld_park = h->io_stride;
   T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
   T.promote_out = 1;
+  T.p_iter = h->promote_buffer ? h->d_piter : nullptr;
+  T.refill_floor = h->refill_floor_f32;
+  T.compact_gap = (T.p_iter && B >= h->compact_min_batch) ? h->compact_gap : 0; T.compact_cooldown = h->compact_cooldown;
   hipLaunchKernelGGL((mpc_solve_kernel<true, float, 1, RIO, RIO>), dim3(waves), dim3(kBlock), staging_lds_bytes<float>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws32, h->ws_stride_f32, T);
   MPC_HIP_CHECK(hipGetLastError());
@@ -1355,6 +1408,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.out_inst = h->d_list + 2 * h->io_stride; U.out_src = h->d_list + 3 * h->io_stride; U.out_park = h->d_park + (int64_t)kParkRows * h->io_stride;
   U.src_ws = ws32; U.src_tile_reals = h->ws_stride_f32;
   U.resume = 1; U.promote_in = 1;
+  U.p_iter = h->promote_buffer ? h->d_piter : nullptr;
   U.refill_min = h->finish_refill_min; U.refill_wait = h->finish_refill_wait;
   U.compact_gap = B >= h->compact_min_batch ? h->compact_gap : 0;
   U.compact_cooldown = h->compact_cooldown;
@@ -1486,7 +1540,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     T.src_ws = rd ? h->ws2 : h->ws;
     T.pass_cut = p < n_cuts ? h->cuts[p] : 0;
     T.resume = p > 0;
-    T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
+    T.refill_min = h->refill_min; T.refill_wait = h->refill_wait; T.refill_floor = h->refill_floor;
     T.compact_cooldown = h->compact_cooldown;
     T.compact_gap = (n_cuts == 0 && B >= h->compact_min_batch) ? h->compact_gap : 0;     /* (a phase that parks keeps iterates in its columns) */
     tail_fields(T);

@@ -525,6 +525,43 @@ def test_lane_compaction_is_bitwise_identical(pkg, golden_dir, waypoints, torch_
             os.environ["MPC_LANE_COMPACT"] = old
 
 
+def test_f32_phase_refill_is_bitwise_identical(pkg, golden_dir, waypoints, torch_dev):
+    """MpcParams.f32_phase_refill: the lanes of the fp32 phase of a mixed-precision solve hand their promoted iterates over through
+    a buffer of their own (at the wave's hand-over point, all waiting lanes at once) and take further instances; the fp64 phase
+    reads the buffer instead of the fp32 workspace's columns.  Not a bit may change: fp32-array handles with weight sweeps, the
+    fp32 start of an fp64 handle (N = 10 and the automatic N = 25), with deferred tails, with and without lane compaction."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+
+    def solve(q, b, w, dt_):
+        B = b["state"].shape[1]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=dt_)
+        with pkg.BatchedMPC(q, B, device=0) as mpc:
+            res = []
+            for _ in range(2):                             # the second call reuses the buffer
+                r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=None if w is None else t(w), want_traj=True)
+                mpc.tail_wait()
+                torch.cuda.synchronize()
+                res.append({k: v.cpu().numpy() for k, v in r.items()})
+            for key in ("out", "traj", "status", "iters"):
+                assert np.array_equal(res[0][key], res[1][key]), key
+            return res[0]
+
+    for N, dt, B, sweep, prec, f32s, cut, compact in ((10, 0.1, 16384 + 5, True, pkg.PRECISION_F32, 0, 0, 2), (10, 0.1, 16384, True, pkg.PRECISION_F32, 0, 12, 2),
+                                                      (10, 0.1, 16384, False, pkg.PRECISION_F64, 1, 0, 2), (25, 0.05, 4096, False, pkg.PRECISION_F64, 2, 0, 0),
+                                                      (10, 0.1, 8192, True, pkg.PRECISION_F64, 1, 12, 0)):
+        q = params.copy(); q.N = N; q.dt = dt; q.precision = prec; q.f64_f32_start = f32s; q.tail_cut = cut; q.lane_compact = compact
+        b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=93)
+        w = pkg.scenarios.weight_sweep(B, q, seed=94, velocity_weights=(0.0, 1.0, 100.0)) if sweep else None
+        dt_ = torch.float32 if prec == pkg.PRECISION_F32 else torch.float64
+        r0 = solve(q, b, w, dt_)
+        q1 = q.copy(); q1.f32_phase_refill = 1
+        r1 = solve(q1, b, w, dt_)
+        for key in ("out", "traj", "status", "iters"):
+            assert np.array_equal(r1[key], r0[key]), (N, prec, f32s, cut, key)
+        assert (r0["status"] == 0).mean() > 0.99
+
+
 def test_tile_pool_is_bitwise_identical_and_used(pkg, golden_dir, waypoints, torch_dev):
     """MPC_TILE_POOL=1: waves take their workspace tile from a per-XCD pool shared by all handles instead of their
     handle's own workspace.  Three handles on three streams, several rounds without a pause in between (so tiles change

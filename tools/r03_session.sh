@@ -465,5 +465,39 @@ mu)   # the N = 25 share as shipped (fp32 start) with deferred tails: run length
   for st in 80 400 1000; do for c in 12 16 20; do run n25_f32s_c${c}_s$st $N25 --steps $st --tail-cut $c --tail-ring 64; done; done
   run n25_f32s_c0_s400 $N25 --steps 400
   ;;
+pb)   # mixed precision: the promoted iterates in a buffer of their own (the fp32 phase's lanes are free after the hand-over) against in their columns
+  timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "f32 or mixed or lane_compaction or deferred_tails_are_bitwise or soak" > $OUT/r03pb_pytest.log 2>&1; rc=$?; echo "pytest exit=$rc" | tee -a $P; tail -5 $OUT/r03pb_pytest.log
+  if [ $rc -ne 0 ]; then exit 1; fi
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  for rep in a b; do
+    run plain_$rep --steps 100
+    for pb in 0 1; do for nfl in 2 3 4; do MPC_PROMOTE_BUFFER=$pb run head_f32s_pb${pb}_i${nfl}_$rep --steps 100 --f64-f32-start --inflight $nfl; done; done
+    for pb in 0 1; do MPC_PROMOTE_BUFFER=$pb run n25_f32s_pb${pb}_$rep --config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8 --steps 400 --tail-cut 12 --tail-ring 64; done
+    for pb in 0 1; do MPC_PROMOTE_BUFFER=$pb run w32_mixed_pb${pb}_$rep --weights-sweep --precision f32 --no-traj --batch 131072 --steps 100 --inflight 8 --tail-cut 12; done
+  done
+  ;;
+rf)   # refill floor: no further takes once fewer lanes than this are running (plain solve; fp32 phase of a mixed solve with the promote buffer)
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations']))" | tee -a $P; }
+  for fl in 0 8 16 32 48; do MPC_REFILL_FLOOR=$fl run plain_floor$fl --steps 100; done
+  MPC_PROMOTE_BUFFER=0 run head_f32s_pb0 --steps 100 --f64-f32-start --inflight 3
+  for fl in 0 16 32 48 64; do MPC_REFILL_FLOOR_F32=$fl run head_f32s_floor$fl --steps 100 --f64-f32-start --inflight 3; done
+  MPC_PROMOTE_BUFFER=0 run n25_f32s_pb0 --config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8 --steps 400 --tail-cut 12 --tail-ring 64
+  for fl in 0 16 32 48 64; do MPC_REFILL_FLOOR_F32=$fl run n25_f32s_floor$fl --config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8 --steps 400 --tail-cut 12 --tail-ring 64; done
+  MPC_PROMOTE_BUFFER=0 run w32_mixed_pb0 --weights-sweep --precision f32 --no-traj --batch 131072 --steps 100 --inflight 8 --tail-cut 12
+  for fl in 0 16 32 48 64; do MPC_REFILL_FLOOR_F32=$fl run w32_mixed_floor$fl --weights-sweep --precision f32 --no-traj --batch 131072 --steps 100 --inflight 8 --tail-cut 12; done
+  ;;
+rg)   # what decides whether the promote buffer pays: batch size, weights, precision at the ABI
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-30s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations']))" | tee -a $P; }
+  for pb in 0 1; do
+    export MPC_PROMOTE_BUFFER=$pb
+    run f32io_plainw_B65536_pb$pb --precision f32 --no-traj --batch 65536 --steps 100 --inflight 4
+    run f32io_plainw_B131072_pb$pb --precision f32 --no-traj --batch 131072 --steps 100 --inflight 4
+    run f32io_sweep_B65536_pb$pb --weights-sweep --precision f32 --no-traj --batch 65536 --steps 100 --inflight 8 --tail-cut 12
+    run f32io_sweep_B131072_i4_notail_pb$pb --weights-sweep --precision f32 --no-traj --batch 131072 --steps 100 --inflight 4
+    run f64io_sweep_B65536_pb$pb --weights-sweep --batch 65536 --steps 100 --inflight 4 --f64-f32-start --tail-cut 12
+    run f64io_head_B131072_pb$pb --batch 131072 --steps 60 --inflight 3 --f64-f32-start
+  done
+  unset MPC_PROMOTE_BUFFER
+  ;;
 esac
 echo done | tee -a $P
