@@ -499,5 +499,10 @@ rg)   # what decides whether the promote buffer pays: batch size, weights, preci
   done
   unset MPC_PROMOTE_BUFFER
   ;;
+sx)   # the whole gpu suite under the aggressive settings of the opt-in / tunable machinery
+  MPC_LANE_COMPACT=1 MPC_LANE_COMPACT_COOLDOWN=0 timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/r03sx_compact.log 2>&1; echo "lane_compact 1 / cooldown 0: exit=$?" | tee -a $P; tail -4 $OUT/r03sx_compact.log
+  MPC_PROMOTE_BUFFER=1 timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/r03sx_buffer.log 2>&1; echo "promote buffer forced: exit=$?" | tee -a $P; tail -4 $OUT/r03sx_buffer.log
+  MPC_MIXED=1 MPC_PROMOTE_BUFFER=1 timeout -k 10 1000 python -m pytest tests -m gpu -q -k "matches_oracle or scipy or full_size_properties or soak or test_cpp or horizon_extremes or rollout or plot_anchors or run_path or leave_the_central_path" > $OUT/r03sx_mixed.log 2>&1; echo "fp32 start forced on every fp64 handle + buffer: exit=$?" | tee -a $P; tail -6 $OUT/r03sx_mixed.log
+  ;;
 esac
 echo done | tee -a $P
