@@ -504,5 +504,12 @@ sx)   # the whole gpu suite under the aggressive settings of the opt-in / tunabl
   MPC_PROMOTE_BUFFER=1 timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/r03sx_buffer.log 2>&1; echo "promote buffer forced: exit=$?" | tee -a $P; tail -4 $OUT/r03sx_buffer.log
   MPC_MIXED=1 MPC_PROMOTE_BUFFER=1 timeout -k 10 1000 python -m pytest tests -m gpu -q -k "matches_oracle or scipy or full_size_properties or soak or test_cpp or horizon_extremes or rollout or plot_anchors or run_path or leave_the_central_path" > $OUT/r03sx_mixed.log 2>&1; echo "fp32 start forced on every fp64 handle + buffer: exit=$?" | tee -a $P; tail -6 $OUT/r03sx_mixed.log
   ;;
+uf)   # the unfiltered population with the fp32 start (+ refill) and deferred tails
+  run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --population survey --tail-ring 64 --steps 2000 "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  run plain_c20 --tail-cut 20
+  for c in 8 12 16; do run f32s_c${c}_i3 --f64-f32-start --inflight 3 --tail-cut $c; done
+  for c in 8 12 16; do run f32s_refill_c${c}_i3 --f64-f32-start --f32-phase-refill --inflight 3 --tail-cut $c; done
+  run f32s_refill_c12_i4 --f64-f32-start --f32-phase-refill --inflight 4 --tail-cut 12
+  ;;
 esac
 echo done | tee -a $P
