@@ -336,17 +336,18 @@ LEGS = {
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
                   dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")),
-    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64, as shipped: "
-                        "MpcParams.f64_f32_start = auto runs the early iterations of horizons of 15 steps and more on the fp32 record (the long-horizon "
-                        "workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, tail_cut=12, steps=600,
-                             f32_start=True,
-                             note="an instance the fp64 phase cannot finish from the fp32 iterate (1-3 in 8 192) is solved again as the single-phase solve does it: "
-                                  "a chain of 134 iterations here, which deferred tails (tail_cut 12) take out of the launches; without them 7.0-7.3 M, and the "
-                                  "drain of the last tails is inside the clock: 7.2 / 9.3 / 9.7 M solves/s over 80 / 400 / 1000 batches")),
-    "configs_3_share_single_phase": ("the same share with f64_f32_start = 0 (every iteration in fp64), deferred tails, four batches in flight",
-                                     dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24,
-                                          steps=80)),
+    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 (every iteration in fp64: the "
+                        "shipped default), deferred tails, four batches in flight",
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24, steps=80)),
+    "configs_3_share_f32_start": ("the same share with MpcParams.f64_f32_start = MPC_F32_START_AUTO (opt-in): horizons of 15 steps and more run their early iterations "
+                                  "on the fp32 record (the long-horizon workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
+                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, tail_cut=12, steps=600,
+                                       f32_start=True,
+                                       note="opt-in because on the hard instances of SURVEY's unfiltered population the fp32 start can lead to another local minimum (5 of 32 768 at "
+                                            "N = 25, 2 more converge where the single-phase solve and the oracle fail; the single-phase solve matches the oracle on all of them).  An "
+                                            "instance the fp64 phase cannot finish from the fp32 iterate (1-3 in 8 192) is solved again as the single-phase solve does it: a chain of 134 "
+                                            "iterations here, which deferred tails (tail_cut 12) take out of the launches; the drain of the last tails is inside the clock: 7.2 / 9.3 / "
+                                            "9.7 M solves/s over 80 / 400 / 1000 batches")),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
                         "(epsi / v incl. 0 / delta / a)",
                         dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, f32_refill=True, note="MPC_PRECISION_F32 as shipped, with the two switches for heavy-tailed workloads (tail_cut 12, f32_phase_refill: 18 -> 22 M solves/s): fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "

@@ -103,7 +103,7 @@ extern "C" int mpc_params_default(MpcParams *p) {
   p->honor_original_bounds = 1;
   p->bound_relax_factor = 1e-8;            /* IPOPT default */
   p->tail_cut = 0; p->tail_ring = 32; p->tail_capacity = 0;
-  p->f32_finish = 1; p->f64_f32_start = MPC_F32_START_AUTO; p->mixed_switch_mu = 2e-5;
+  p->f32_finish = 1; p->f64_f32_start = MPC_F32_START_OFF; p->mixed_switch_mu = 2e-5;
   p->lane_compact = 2; p->f32_phase_refill = 0;
   return MPC_OK;
 }

@@ -94,13 +94,14 @@ def test_f32_finish_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, 
 
 
 def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, host_twin, golden_dir, waypoints):
-    """MpcParams.f64_f32_start = MPC_F32_START_AUTO (the default): fp64 handles with N >= 15 run their early iterations on the fp32
+    """MpcParams.f64_f32_start = MPC_F32_START_AUTO (opt-in): fp64 handles with N >= 15 run their early iterations on the fp32
     record.  The whole N = 25 batch of the full-size soak (8 192 instances) through the host replay of the two phases: same status
     as the single-phase solve on every instance, outputs within the fp64 tolerances -- including the instances the fp64 phase
     cannot finish from where fp32 left them (a failed line search on the device before this rule existed): those are solved again
     from the start point exactly as the single-phase solve does it, and so return its status and its point."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
-    assert params.f64_f32_start == 2 and params.N >= 15
+    assert params.f64_f32_start == 0                      # off by default (forks on the hard instances of SURVEY's unfiltered population)
+    params.f64_f32_start = 2                              # MPC_F32_START_AUTO: on from N = 15
     B = 8192
     b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=103)
     r = twin_solve_mixed_f64(host_twin, params, b)
@@ -111,6 +112,26 @@ def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, 
     again = np.nonzero(r["iters"] - r["iters_f32"] > 40)[0]     # the fp64 phase did not just finish them: restarts from the start point
     assert 1 <= len(again) <= 8 and (r["iters_f32"] > 0).all(), (again, r["iters"][again], r0["iters"][again])
     assert abs(r["iters"].mean() - r0["iters"].mean()) < 0.5 and r["iters"].max() <= r0["iters"].max() + 60
+
+
+def test_single_phase_solve_matches_the_oracle_where_the_f32_start_forks(pkg, host_twin, golden_dir, waypoints):
+    """Why f64_f32_start is opt-in.  configs[3]'s share drawn with SURVEY 8d's rejection only (32 768 instances, N = 25): on seven
+    hard instances (50-170 iterations) the fp32 start ends somewhere else -- five in another local minimum, two converge where
+    single-phase solve and oracle report a failed line search.  The shipped default, the single-phase solve, is the oracle's on
+    every one of them: status, iteration count, point."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
+    b = pkg.scenarios.lake_track_batch(32768, params, waypoints, stream=3, filtered="survey")
+    hard = [6974, 7225, 8421, 15960, 18245, 18943, 25724]
+    sub = {k: np.ascontiguousarray(b[k][..., hard]) for k in ("state", "coeffs", "yaw_lo", "yaw_hi")}
+    r0 = twin_solve(host_twin, params, sub)
+    ref = oracle_solve_batch(O.load_config("config-stable.json", N=25, dt=0.05), sub, range(len(hard)), opt=O.default_options(max_iter=params.max_iter))
+    assert list(ref["status"]) == [2, 0, 0, 0, 2, 0, 0]
+    assert np.array_equal(r0["status"], ref["status"]) and np.abs(r0["iters"] - ref["iters"]).max() <= 1
+    assert np.abs(r0["out"][:8] - ref["out"][:8]).max() <= 1e-6
+    q = params.copy(); q.f64_f32_start = 2
+    r = twin_solve_mixed_f64(host_twin, q, sub)
+    differs = (r["status"] != ref["status"]) | (np.abs(r["out"][:8] - ref["out"][:8]).max(0) > 1e-6)
+    assert differs.sum() >= 5                                   # (if this ever stops holding, the default can be reconsidered)
 
 
 def test_f32_pure_twin_weight_sweep_matches_fp64_oracle(pkg, host_twin, golden_dir, waypoints):

@@ -658,8 +658,8 @@ def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_
     over = dict(N=25, dt=0.05) if case.startswith("N25") else {}
     cfgname = "config-stable.json" if case.startswith("N25") else "config-fast.json"
     params = pkg.params_from_json(os.path.join(golden_dir, cfgname), **over)
-    if case == "N25plain":
-        params.f64_f32_start = 0                              # "N25" itself runs as shipped: long horizons start on the fp32 record
+    if case == "N25":
+        params.f64_f32_start = 2                              # MPC_F32_START_AUTO: long horizons start on the fp32 record ("N25plain": as shipped)
     f32 = case in ("f32", "mixed")
     if f32:
         params.precision = pkg.PRECISION_F32

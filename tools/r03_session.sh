@@ -379,7 +379,7 @@ except Exception as e:
 PY
   }
   for rep in a b; do for g in 0 1 2 3 4; do
-    for l in configs_3_share_single_phase configs_3_share unfiltered configs_4_share_pure_fp32; do MPC_LANE_COMPACT=$g leg ${l}_g${g}_$rep $l; done
+    for l in configs_3_share configs_3_share_f32_start unfiltered configs_4_share_pure_fp32; do MPC_LANE_COMPACT=$g leg ${l}_g${g}_$rep $l; done
   done; done
   ;;
 lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N = 25 share with and without)
@@ -387,7 +387,7 @@ lf)   # lane compaction: quick A/B of a build (bitwise test, headline and the N 
   if [ $rc -ne 0 ]; then exit 1; fi
   for rep in a b c; do for g in 0 2; do
     MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline g=$g $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share_single_phase g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$g timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share g=$g $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
   done; done
   ;;
 us)   # the unfiltered population with deferred tails: run length (the drain of the last tails is inside the clock) and the cut
@@ -410,7 +410,7 @@ lg)   # lane compaction: gap x cooldown (passes without another move), headline 
   for rep in a b; do for gc in "0 2" "2 2" "2 0" "1 0" "1 1" "3 0"; do
     set -- $gc
     MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share_single_phase gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+    MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
   done; done
   ;;
 lh)   # same-box A/B of the builds in gpurun_in/ (libmpc_<tag>.so): headline and the N = 25 share, lane compaction off / on
@@ -420,7 +420,7 @@ lh)   # same-box A/B of the builds in gpurun_in/ (libmpc_<tag>.so): headline and
     for gc in "0 2" "2 2" "2 0" "1 0"; do
       set -- $gc
       MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 100 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t headline gap=$1 cooldown=$2 $rep  %.3f M' % (r['value']/1e6))" | tee -a $P
-      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share_single_phase 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t configs_3_share_single_phase gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
+      MPC_LANE_COMPACT=$1 MPC_LANE_COMPACT_COOLDOWN=$2 timeout -k 10 300 python bench.py --leg configs_3_share 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   $t configs_3_share gap=$1 cooldown=$2 $rep  %.3f M' % (r['solves_per_s']/1e6))" | tee -a $P
     done
   done; done
   cp /tmp/libmpc_keep.so carnd-mpc-project_amd/lib/libmpc_amd.so
@@ -510,6 +510,14 @@ uf)   # the unfiltered population with the fp32 start (+ refill) and deferred ta
   for c in 8 12 16; do run f32s_c${c}_i3 --f64-f32-start --inflight 3 --tail-cut $c; done
   for c in 8 12 16; do run f32s_refill_c${c}_i3 --f64-f32-start --f32-phase-refill --inflight 3 --tail-cut $c; done
   run f32s_refill_c12_i4 --f64-f32-start --f32-phase-refill --inflight 4 --tail-cut 12
+  ;;
+n3)   # configs[3] share drawn with SURVEY's rejection only: single phase against the fp32 start, deferred tails
+  run() { tag=$1; shift; timeout -k 10 400 python bench.py --no-legs --no-cpu-baseline --no-host-leg --population survey --tail-ring 64 --config config-stable.json --N 25 --dt 0.05 --batch 32768 "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  run plain_c0_i4 --steps 40 --inflight 4
+  for c in 16 24 32; do run plain_c${c}_i4 --steps 400 --inflight 4 --tail-cut $c; done
+  run f32s_c0_i8 --steps 40 --inflight 8 --f64-f32-start
+  for c in 12 16 24; do run f32s_c${c}_i8 --steps 400 --inflight 8 --f64-f32-start --tail-cut $c; done
+  run f32s_refill_c12_i8 --steps 400 --inflight 8 --f64-f32-start --f32-phase-refill --tail-cut 12
   ;;
 esac
 echo done | tee -a $P
