@@ -339,6 +339,10 @@ LEGS = {
     "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 (every iteration in fp64: the "
                         "shipped default), deferred tails, four batches in flight",
                         dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24, steps=80)),
+    "configs_3_share_unfiltered": ("the same share drawn with SURVEY.md 8d's rejection only (37 k draws for 32 768): 16 instances per batch end at the iteration cap or with a "
+                                   "failed line search after up to 238 iterations (the oracle's verdict on the same instances), deferred tails",
+                                   dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey",
+                                        tail_cut=24, steps=400, note="0.70 M solves/s without deferred tails (47 ms per batch); tail_cut 16 overflows the queue (capacity B / 8)")),
     "configs_3_share_f32_start": ("the same share with MpcParams.f64_f32_start = MPC_F32_START_AUTO (opt-in): horizons of 15 steps and more run their early iterations "
                                   "on the fp32 record (the long-horizon workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
                                   dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, tail_cut=12, steps=600,
@@ -352,6 +356,10 @@ LEGS = {
                         "(epsi / v incl. 0 / delta / a)",
                         dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, f32_refill=True, note="MPC_PRECISION_F32 as shipped, with the two switches for heavy-tailed workloads (tail_cut 12, f32_phase_refill: 18 -> 22 M solves/s): fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
                                   "(tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")),
+    "configs_4_share_unfiltered": ("the same share drawn with SURVEY.md 8d's rejection only: 44 instances per batch end at the iteration cap or with a failed line search "
+                                   "(chains of up to 426 iterations through both phases), deferred tails and f32_phase_refill",
+                                   dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, population="survey", tail_cut=12, steps=150,
+                                        f32_refill=True, note="3.3 M solves/s without deferred tails (39 ms per batch); the pure fp32 solver on this population: 28 M with tail_cut 24")),
     "configs_4_share_pure_fp32": ("the same share with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances), deferred tails",
                                   dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=24, steps=150,
                                        f32_pure=True)),

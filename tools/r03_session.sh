@@ -519,5 +519,14 @@ n3)   # configs[3] share drawn with SURVEY's rejection only: single phase agains
   for c in 12 16 24; do run f32s_c${c}_i8 --steps 400 --inflight 8 --f64-f32-start --tail-cut $c; done
   run f32s_refill_c12_i8 --steps 400 --inflight 8 --f64-f32-start --f32-phase-refill --tail-cut 12
   ;;
+n4)   # configs[4] share drawn with SURVEY's rejection only
+  run() { tag=$1; shift; timeout -k 10 400 python bench.py --no-legs --no-cpu-baseline --no-host-leg --population survey --tail-ring 64 --weights-sweep --precision f32 --no-traj --batch 131072 "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  run mixed_c12_refill_i8 --steps 150 --inflight 8 --tail-cut 12 --f32-phase-refill
+  run mixed_c12_i8 --steps 150 --inflight 8 --tail-cut 12
+  run mixed_c0_i4 --steps 40 --inflight 4
+  run pure_c24_i4 --steps 150 --inflight 4 --tail-cut 24 --f32-pure
+  run pure_c0_i4 --steps 40 --inflight 4 --f32-pure
+  timeout -k 10 300 python bench.py --leg configs_3_share_unfiltered 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   leg configs_3_share_unfiltered  %.3f M  %s' % (r['solves_per_s']/1e6, r['status_counts']))" | tee -a $P
+  ;;
 esac
 echo done | tee -a $P
