@@ -340,7 +340,8 @@ LEGS = {
                         "shipped default), deferred tails, four batches in flight",
                         dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=24, steps=80)),
     "configs_3_share_unfiltered": ("the same share drawn with SURVEY.md 8d's rejection only (37 k draws for 32 768): 16 instances per batch end at the iteration cap or with a "
-                                   "failed line search after up to 238 iterations (the oracle's verdict on the same instances), deferred tails",
+                                   "failed line search after up to 238 iterations (oracle and CPU build of the solver: 6 at the cap + 11 failed line searches, the same 17 "
+                                   "instances; the device's own rounding brings one of the six in just under the cap), deferred tails",
                                    dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey",
                                         tail_cut=24, steps=400, note="0.70 M solves/s without deferred tails (47 ms per batch); tail_cut 16 overflows the queue (capacity B / 8)")),
     "configs_3_share_f32_start": ("the same share with MpcParams.f64_f32_start = MPC_F32_START_AUTO (opt-in): horizons of 15 steps and more run their early iterations "
