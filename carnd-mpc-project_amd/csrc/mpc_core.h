@@ -1366,7 +1366,7 @@ struct Solver {
   enum { MPC_RUNNING = -1, MPC_PROMOTE = -2 };   /* PROMOTE: the fp32 phase of a mixed-precision solve hands the instance to fp64 */
   enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
   enum { kMaxPolish = 6 };
-  enum { kPromoteIterCap = 40 };   /* mixed precision: iterations after which the fp32 phase hands an instance over whatever its barrier parameter */
+  enum { kPromoteIterCap = 16 };   /* mixed precision: the fp32 phase's allowance per instance (the bulk hands over after 8-12 iterations); one that uses it up is solved in fp64 from the start point */
   /* state of the interior-point loop (see step()) */
   int phase, iter, n_polish;
   bool ls_start, tiny;
@@ -1378,6 +1378,7 @@ struct Solver {
   static constexpr bool kCanPromote = sizeof(R) == 4;   /* only the fp32 solver ever hands over: none of it is in the fp64 kernels */
   R promote_mu = R(0.0);
   int promote_cap = kPromoteIterCap;
+  mutable bool promote_clean = true;   /* the hand-over came where it should (barrier parameter or tol_f32 reached), not out of trouble (allowance used up, line search or inertia correction out of single precision) */
   bool keep_theta = false;
   R out_step;     /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   R out_prev;     /* the same of the step before (fp32 wants two quiet steps in a row) */
@@ -1465,7 +1466,7 @@ struct Solver {
    * rounding into the dual residual, slacks of a few ulp cannot shrink), so a point whose optimality error is within
    * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
   MPC_HD int line_search_failed() const {
-    if ((kCanPromote && promote_mu > R(0.0))) return MPC_PROMOTE;   /* out of step length in single precision: the iterate goes on in fp64 */
+    if ((kCanPromote && promote_mu > R(0.0))) { promote_clean = false; return MPC_PROMOTE; }   /* out of step length in single precision */
     if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
     /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
     if (n_polish > 0 && kkt_error(E, R(0.0)) <= tol) return MPC_STATUS_SUCCESS;
@@ -1493,7 +1494,7 @@ struct Solver {
         if (!(E0 == E0)) return MPC_STATUS_NUMERIC;
         /* as far as this precision is asked to go -- or an instance that is taking long: the stragglers (steps of a few per
          * cent against a bound for dozens of iterations) are where the noise of fp32 steps costs most; they go on in fp64 */
-        if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= promote_cap)) return MPC_PROMOTE;
+        if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= promote_cap)) { promote_clean = E0 <= tol; return MPC_PROMOTE; }
         if (E0 <= tol) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
@@ -1514,7 +1515,7 @@ struct Solver {
           tau = mpc_max(IC::tau_min, R(1.0) - mu);
           nf = 0;
         }
-        if ((kCanPromote && promote_mu > R(0.0)) && mu <= promote_mu) return MPC_PROMOTE;   /* the barrier problems below are the other solver's */
+        if ((kCanPromote && promote_mu > R(0.0)) && mu <= promote_mu) { promote_clean = true; return MPC_PROMOTE; }   /* the barrier problems below are the other solver's */
 #if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
         printf("it %3d f=%.8g theta=%.3e dinf=%.3e cmin=%.2e cmax=%.2e mu=%.2e E0=%.3e nf=%d\n", iter, E.f, E.theta,
                E.dinf, E.cmin, E.cmax, mu, E0, nf);
@@ -1529,7 +1530,7 @@ struct Solver {
         if (lsm) { okb = false; break; }
         if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
         else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
-        if (dw > IC::dw_max || ++tries > 100) return (kCanPromote && promote_mu > R(0.0)) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH;
+        if (dw > IC::dw_max || ++tries > 100) { promote_clean = false; return (kCanPromote && promote_mu > R(0.0)) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH; }
       }
       if (okb) forward();
       dw_cur = dw;

@@ -117,6 +117,7 @@ struct MpcPhase {
    * fp64 solver resuming from that list: the parked iterate, in the fp32 record layout of src_ws (tiles of src_tile_reals
    * floats), is converted field by field, the point is re-evaluated in fp64 and the solve goes on to tol and the polish. */
   int32_t promote_out, promote_in;
+  int32_t promote_cap;      /* iterations the fp32 phase may spend on an instance (0: Solver::kPromoteIterCap) */
   int64_t src_tile_reals;
   /* The promoted iterates travel in a buffer of their own, [list position / 64][N-1][IT_SZ][64] reals of the fp32 record:
    * a lane that has handed its instance over is free at once -- it takes the next instance while the launch has any, and
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
   ws.lane = threadIdx.x;
   ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
-  if (T.promote_out) S.promote_mu = (R)P.mixed_switch_mu;
+  if (T.promote_out) { S.promote_mu = (R)P.mixed_switch_mu; if (T.promote_cap > 0) S.promote_cap = T.promote_cap; }
   int64_t i = 0;
   bool have = false, more = true, fin = false;   /* holds a running instance / may still get one / holds a finished one */
   bool queue_full = false;                       /* deferred tails: the batch's queue slot has no room left */
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
             }
             const bool from_scratch = T.promote_in && T.in_park[pos + 35 * T.ld_park] != 0.0;   /* the fp32 phase gave up on it */
             const int s0 = S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, !T.resume || from_scratch);
-            if (from_scratch) { S.begin(true); attempt = 0; it_total = 0; passes = 0; have = true; }
+            if (from_scratch) { S.begin(true); attempt = 0; it_total = (int)T.in_park[pos + 23 * T.ld_park] + (int)T.in_park[pos + 29 * T.ld_park]; passes = 0; have = true; }   /* (the fp32 phase's iterations count) */
             else if (T.resume) {
               /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
               const double *pk = T.in_park + pos;
@@ -433,9 +434,14 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
     if (have) {
       const int r = S.step();
       ++passes;
+      /* Mixed precision.  Only a CLEAN hand-over is continued by the fp64 solver (the fp32 phase reached the switch value of the
+       * barrier parameter, or tol_f32).  One that comes out of trouble -- the iteration allowance used up, line search or inertia
+       * correction out of single precision, not-a-number -- sends the instance to the fp64 solver FROM THE START POINT (row 35 of
+       * the parked scalars): on hard instances the fp32 iterates lead into other local minima than the fp64 ones (SURVEY's
+       * unfiltered populations: 7 of 32 768 at N = 25, 24 of 65 536 at N = 10 with the old rule; none with this one). */
       if ((r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) && T.p_iter) {
         /* mixed precision: this phase has taken the instance as far as it is asked to; it waits for the wave's next hand-over */
-        fin = true; fin_status = r == SV::MPC_PROMOTE ? kFinPromote : kFinScratch; have = false;
+        fin = true; fin_status = (r == SV::MPC_PROMOTE && S.promote_clean) ? kFinPromote : kFinScratch; have = false;
       } else if (r == SV::MPC_PROMOTE || (T.promote_out && r == MPC_STATUS_NUMERIC)) {
         /* the same with the iterate left in its column (MPC_PROMOTE_BUFFER=0): the next phase's solver takes over.
          * Not-a-number in the fp32 phase (states far from the origin late in a closed loop: x^4 terms, lost digits) is not a
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
         double *pk = T.out_park + pos;
         const int64_t lp = T.ld_park;
         S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
-        pk[35 * lp] = r == SV::MPC_PROMOTE ? 0.0 : 1.0;
+        pk[35 * lp] = (r == SV::MPC_PROMOTE && S.promote_clean) ? 0.0 : 1.0;
         have = false; more = false; col_busy = true;     /* the column keeps the parked iterate: this lane takes nothing else */
       } else if (r != SV::MPC_RUNNING) {
         if (attempt < 0 && r != MPC_STATUS_SUCCESS) {
@@ -859,6 +865,7 @@ struct MpcHandle {
   void *ws2 = nullptr;
   double *d_park = nullptr;   /* [2][PARK_ROWS][io_stride] */
   void *d_piter = nullptr;    /* mixed precision: the promoted iterates, [io_stride / 64][N-1][IT_SZ of the fp32 record][64] floats */
+  int promote_cap = 0;        /* MPC_PROMOTE_CAP (measurement aid; 0 = Solver::kPromoteIterCap) */
   bool promote_buffer = false, promote_env = false;   /* MpcParams.f32_phase_refill (MPC_PROMOTE_BUFFER in the environment overrides: measurement aid) */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
@@ -1070,6 +1077,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (const char *e11 = getenv("MPC_PROMOTE_BUFFER")) { h->promote_buffer = atoi(e11) != 0; h->promote_env = true; }
   if (const char *e12 = getenv("MPC_REFILL_FLOOR")) h->refill_floor = atoi(e12);
   if (const char *e13 = getenv("MPC_REFILL_FLOOR_F32")) h->refill_floor_f32 = atoi(e13);
+  if (const char *e15 = getenv("MPC_PROMOTE_CAP")) h->promote_cap = atoi(e15);
   if (const char *e6 = getenv("MPC_FINISH_DIV")) { h->finish_div = atoi(e6); if (h->finish_div < 1) h->finish_div = 1; }
   if (const char *e7 = getenv("MPC_FINISH_REFILL_MIN")) { h->finish_refill_min = atoi(e7); if (h->finish_refill_min < 1) h->finish_refill_min = 1; }
   if (const char *e8 = getenv("MPC_FINISH_REFILL_WAIT")) { h->finish_refill_wait = atoi(e8); if (h->finish_refill_wait < 0) h->finish_refill_wait = 0; }
@@ -1395,6 +1403,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   T.out_inst = h->d_list; T.out_src = h->d_list + h->io_stride; T.out_park = h->d_park; T.ld_park = h->io_stride;
   T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
   T.promote_out = 1;
+  T.promote_cap = h->promote_cap;
   T.p_iter = h->promote_buffer ? h->d_piter : nullptr;
   T.refill_floor = h->refill_floor_f32;
   T.compact_gap = (T.p_iter && B >= h->compact_min_batch) ? h->compact_gap : 0; T.compact_cooldown = h->compact_cooldown;

@@ -204,6 +204,12 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
       for (;;) {
         const int r = in_double ? D.step() : A.step();
         if (r == SF::MPC_RUNNING) continue;
+        if (r == SF::MPC_PROMOTE && !A.promote_clean) {   /* a hand-over out of trouble (allowance used up, line search / inertia out of single precision): from the start point in fp64 */
+          if (iters_f32) iters_f32[i] = A.iter + it_total;
+          (void)D.setup(std_, cfd, (double)yaw_lo[i], (double)yaw_hi[i], wd, true);
+          D.begin(true); attempt = 0; it_total = A.iter; in_double = true;
+          continue;
+        }
         if (r == SF::MPC_PROMOTE) {
           A.park([&park](int q) -> double & { return park[q]; }, attempt, it_total);
           if (iters_f32) iters_f32[i] = A.iter + it_total;
@@ -219,7 +225,7 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
         }
         if (r == MPC_STATUS_NUMERIC && !in_double) {      /* not-a-number in fp32 is not a verdict: fp64 solves it from the start point */
           (void)D.setup(std_, cfd, (double)yaw_lo[i], (double)yaw_hi[i], wd, true);
-          D.begin(true); attempt = 0; it_total = 0; in_double = true;
+          D.begin(true); attempt = 0; it_total = A.iter + it_total; in_double = true;
           continue;
         }
         if (in_double && attempt < 0 && r != MPC_STATUS_SUCCESS) {   /* started by fp32, not finished by fp64: solved again as the single-phase solve does it */

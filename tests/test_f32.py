@@ -89,8 +89,9 @@ def test_f32_finish_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, 
     r64 = twin_solve(host_twin, p64, b, weights=w)
     r = twin_solve_mixed(host_twin, params, b, weights=w)
     _check_f32(r, r64, "mixed vs twin64 (N=%d)" % N, B)
-    assert abs(r["iters"].mean() - r64["iters"].mean()) < 1.0
-    assert r["iters_f32"].mean() > 0.55 * r["iters"].mean()                          # most of the iterations run in fp32
+    # (an instance that uses up the fp32 phase's 16 iterations, or leaves it out of trouble, starts again in fp64: 12 % of a weight sweep)
+    assert abs(r["iters"].mean() - r64["iters"].mean()) < 2.0
+    assert r["iters_f32"].mean() > 0.45 * r["iters"].mean()                          # about half of the iterations run in fp32
 
 
 def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, host_twin, golden_dir, waypoints):
@@ -109,16 +110,18 @@ def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, 
     assert np.array_equal(r["status"], r0["status"]) and (r["status"] == 0).all()
     d = np.abs(r["out"][:8] - r0["out"][:8])
     assert d[6].max() <= 1e-6 and d[7].max() <= 1e-6 and d[:6].max() <= 1e-5 and np.abs(r["traj"] - r0["traj"]).max() <= 1e-5
-    again = np.nonzero(r["iters"] - r["iters_f32"] > 40)[0]     # the fp64 phase did not just finish them: restarts from the start point
-    assert 1 <= len(again) <= 8 and (r["iters_f32"] > 0).all(), (again, r["iters"][again], r0["iters"][again])
+    assert (r["iters_f32"] > 0).all() and (r["iters_f32"] <= 16).all()
     assert abs(r["iters"].mean() - r0["iters"].mean()) < 0.5 and r["iters"].max() <= r0["iters"].max() + 60
 
 
-def test_single_phase_solve_matches_the_oracle_where_the_f32_start_forks(pkg, host_twin, golden_dir, waypoints):
-    """Why f64_f32_start is opt-in.  configs[3]'s share drawn with SURVEY 8d's rejection only (32 768 instances, N = 25): on seven
-    hard instances (50-170 iterations) the fp32 start ends somewhere else -- five in another local minimum, two converge where
-    single-phase solve and oracle report a failed line search.  The shipped default, the single-phase solve, is the oracle's on
-    every one of them: status, iteration count, point."""
+def test_hard_instances_of_the_unfiltered_population_single_phase_and_f32_start(pkg, host_twin, golden_dir, waypoints):
+    """configs[3]'s share drawn with SURVEY 8d's rejection only (32 768 instances, N = 25) has hard instances of 50-170 iterations on
+    which fp32 iterates lead elsewhere than fp64 ones: continued by the fp64 solver from wherever the fp32 phase stopped, five of
+    the seven below ended in another local minimum and two converged where the oracle reports a failed line search.  Hence the
+    rule that only a CLEAN hand-over is continued (barrier parameter at its switch value, or tol_f32 met) and everything else --
+    allowance used up, line search or inertia correction out of single precision -- is solved in fp64 from the start point.
+    Asserted: the single-phase solve (the default) and the fp32 start both give the oracle's status, iteration count (fp64 part)
+    and point on all seven."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
     b = pkg.scenarios.lake_track_batch(32768, params, waypoints, stream=3, filtered="survey")
     hard = [6974, 7225, 8421, 15960, 18245, 18943, 25724]
@@ -130,8 +133,9 @@ def test_single_phase_solve_matches_the_oracle_where_the_f32_start_forks(pkg, ho
     assert np.abs(r0["out"][:8] - ref["out"][:8]).max() <= 1e-6
     q = params.copy(); q.f64_f32_start = 2
     r = twin_solve_mixed_f64(host_twin, q, sub)
-    differs = (r["status"] != ref["status"]) | (np.abs(r["out"][:8] - ref["out"][:8]).max(0) > 1e-6)
-    assert differs.sum() >= 5                                   # (if this ever stops holding, the default can be reconsidered)
+    assert np.array_equal(r["status"], ref["status"])
+    assert np.abs(r["out"][:8] - ref["out"][:8]).max() <= 1e-6
+    assert np.abs((r["iters"] - r["iters_f32"]) - ref["iters"]).max() <= 1 and (r["iters_f32"] <= 16).all()      # solved from the start point in fp64
 
 
 def test_f32_pure_twin_weight_sweep_matches_fp64_oracle(pkg, host_twin, golden_dir, waypoints):

@@ -806,7 +806,9 @@ def test_fp32_start_of_the_fp64_solve_matches_oracle(pkg, golden_dir, waypoints,
     # forks onto another local minimum (flat objectives: velocity weight 0) are counted like in the fp32 mode's tests
     far = ok & ((np.abs(r["out"][6] - plain["out"][6]) > 1e-6) | (np.abs(r["out"][7] - plain["out"][7]) > 1e-5) | (np.abs(r["out"][:6] - plain["out"][:6]).max(0) > 1e-5))
     assert far.sum() <= max(1, B // 2000), np.where(far)[0][:8]
-    assert abs(r["iters"][ok].mean() - plain["iters"][ok].mean()) < 0.5
+    # (the iterations of both phases count; an instance that uses up the fp32 phase's allowance, or leaves it out of trouble, is
+    # solved again from the start point in fp64: a tenth more iterations on a weight sweep, next to nothing on the plain workloads)
+    assert abs(r["iters"][ok].mean() - plain["iters"][ok].mean()) < 2.0
     idx = [int(i) for i in np.where(ok & ~far)[0][::max(1, B // 128)]]
     ref = oracle_solve_batch(O.load_config(config, **over), b, idx, weights=w)
     assert (ref["status"] == 0).all()

@@ -528,5 +528,20 @@ n4)   # configs[4] share drawn with SURVEY's rejection only
   run pure_c0_i4 --steps 40 --inflight 4 --f32-pure
   timeout -k 10 300 python bench.py --leg configs_3_share_unfiltered 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   leg configs_3_share_unfiltered  %.3f M  %s' % (r['solves_per_s']/1e6, r['status_counts']))" | tee -a $P
   ;;
+pc)   # mixed precision with the clean-hand-over rule: the fp32 phase's iteration allowance (MPC_PROMOTE_CAP)
+  timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "f32 or mixed or deferred_tails_are_bitwise or central_path" > $OUT/r03pc_pytest.log 2>&1; rc=$?; echo "pytest exit=$rc" | tee -a $P; tail -5 $OUT/r03pc_pytest.log
+  run() { tag=$1; shift; timeout -k 10 400 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-28s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  run head_plain --steps 100
+  for cap in 40 24 16 12; do
+    export MPC_PROMOTE_CAP=$cap
+    run head_f32s_cap$cap --steps 100 --f64-f32-start --inflight 3
+    run n25_f32s_cap$cap --config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8 --steps 400 --tail-cut 12 --tail-ring 64
+    run n25_f32s_notail_cap$cap --config config-stable.json --N 25 --dt 0.05 --batch 32768 --f64-f32-start --inflight 8 --steps 80
+    run w32_mixed_cap$cap --weights-sweep --precision f32 --no-traj --batch 131072 --steps 100 --inflight 8 --tail-cut 12 --f32-phase-refill
+    run survey_f32s_c20_cap$cap --population survey --tail-ring 64 --steps 1000 --f64-f32-start --inflight 3 --tail-cut 20
+    run n25_survey_f32s_cap$cap --population survey --tail-ring 64 --config config-stable.json --N 25 --dt 0.05 --batch 32768 --steps 400 --inflight 8 --f64-f32-start --tail-cut 24
+  done
+  unset MPC_PROMOTE_CAP
+  ;;
 esac
 echo done | tee -a $P
