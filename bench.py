@@ -329,10 +329,11 @@ LEGS = {
                              "included, is final inside the timed region -- the drain of the last tails, ~100 ms, is part of it, so the rate depends on the run "
                              "length: 30.4 / 32.8 / 34.6 / 35.6 M solves/s at 500 / 1000 / 2000 / 4000 steps on one box")),
     "headline_f32_start": ("the headline workload (configs[2]) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above 2e-5) on the fp32 "
-                           "record, every instance finished by the fp64 solver to the same tol and polish; three batches in flight",
+                           "record, every instance finished by the fp64 solver to the same tol and polish (a hand-over that is not clean -- fp32 allowance of 16 iterations used up, line search out of single "
+                           "precision -- sends the instance to the fp64 solver from the start point); four batches in flight",
                            dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=3, steps=60, f32_start=True,
-                                note="measured 1.12-1.14x the plain fp64 solve on the same box, below the 1.15x set for making it the default: opt-in "
-                                     "(DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")),
+                                note="1.12x the plain fp64 solve on the same box (58.2 vs 51.9 M solves/s), below the 1.15x set for making it the default, and slower than it on "
+                                     "SURVEY's unfiltered population: opt-in (DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")),
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
                   dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight (2 in flight: 4.9-6.4 M solves/s)")),
@@ -348,14 +349,12 @@ LEGS = {
                                   "on the fp32 record (the long-horizon workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
                                   dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, tail_cut=12, steps=600,
                                        f32_start=True,
-                                       note="opt-in because on the hard instances of SURVEY's unfiltered population the fp32 start can lead to another local minimum (5 of 32 768 at "
-                                            "N = 25, 2 more converge where the single-phase solve and the oracle fail; the single-phase solve matches the oracle on all of them).  An "
-                                            "instance the fp64 phase cannot finish from the fp32 iterate (1-3 in 8 192) is solved again as the single-phase solve does it: a chain of 134 "
-                                            "iterations here, which deferred tails (tail_cut 12) take out of the launches; the drain of the last tails is inside the clock: 7.2 / 9.3 / "
-                                            "9.7 M solves/s over 80 / 400 / 1000 batches")),
+                                       note="opt-in because it is not a win everywhere: on this share drawn with SURVEY's rejection only it is slower than the single-phase solve (3.9 against "
+                                            "5.2 M solves/s).  Instances whose hand-over is not clean start again in fp64 (chains of up to 105 iterations here), which deferred tails "
+                                            "(tail_cut 12) take out of the launches; 8.4-9.0 M without them")),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states, fp32 mixed precision, per-instance weight sweep "
                         "(epsi / v incl. 0 / delta / a)",
-                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, f32_refill=True, note="MPC_PRECISION_F32 as shipped, with the two switches for heavy-tailed workloads (tail_cut 12, f32_phase_refill: 18 -> 22 M solves/s): fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=12, steps=150, f32_refill=True, note="MPC_PRECISION_F32 as shipped, with the two switches for heavy-tailed workloads (tail_cut 12, f32_phase_refill: +12-20 %): fp32 iterations down to the barrier parameter 2e-5, every instance finished in fp64 "
                                   "(tests/test_f32.py: 1e-3 on delta0, a0, state against the fp64 path on every instance)")),
     "configs_4_share_unfiltered": ("the same share drawn with SURVEY.md 8d's rejection only: 44 instances per batch end at the iteration cap or with a failed line search "
                                    "(chains of up to 426 iterations through both phases), deferred tails and f32_phase_refill",

@@ -139,13 +139,15 @@ typedef struct MpcParams {
    * MPC_PRECISION_F64 handles: f64_f32_start = 1 runs the same early iterations on the fp32 record (half the
    * workspace bytes) before the fp64 solve takes over; MPC_F32_START_AUTO (2) does so for horizons of
    * N >= MPC_F32_START_AUTO_N steps, where a full device's workspace no longer lives in the Infinity Cache and the bytes
-   * count in full (measured: 1.1x at N = 10-12, 1.3x at 15, 1.4x at 20, 1.5x at 25, 1.9x at 40).  The fp64 phase runs
-   * to tol and the polish, and an instance it cannot finish is solved again the single-phase way, so on well-posed
-   * instances the answers are the single-phase solve's to ~1e-8.  Default 0 (off), because on the hard instances of
-   * SURVEY's unfiltered population (cars far off the fitted stretch of road: 50-200 iterations) the fp32 start can
-   * lead the solve to ANOTHER local minimum: 5 of 32 768 at N = 25, and 2 more converge where the single-phase solve
-   * and the oracle report a failed line search -- while the single-phase solve matches the oracle on all of them to
-   * 1e-12.  A throughput option for callers who accept that. */
+   * count in full.  The fp64 phase runs to tol and the polish.  Only a CLEAN hand-over is continued (the fp32 phase
+   * reached mixed_switch_mu or tol_f32 within 16 iterations); an instance that uses the allowance up or leaves the fp32
+   * phase out of trouble (line search, inertia correction, not-a-number) is solved in fp64 from the start point, and
+   * so is one the fp64 phase cannot finish from the fp32 iterate: on hard instances fp32 iterates lead into other
+   * local minima than fp64 ones.  With that rule the CPU build gives the single-phase solve's status and point (1e-7)
+   * on every instance of SURVEY's unfiltered populations (65 536 at N = 10, 32 768 at N = 25).
+   * Default 0 (off), because it is not a win everywhere: 1.12x on the filtered headline workload (four batches in
+   * flight), 1.5x at N = 25 on the same generator, but slower than the single-phase solve on SURVEY's unfiltered
+   * populations, whose restarted instances are long chains. */
   int32_t f32_finish;
   int32_t f64_f32_start;
   double mixed_switch_mu;          /* default 2e-5 */

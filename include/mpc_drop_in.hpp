@@ -118,8 +118,9 @@ struct Config {
   inline static double tolerance = 1e-8;
   /* One MPC::solve() per telemetry message is a single serial chain on the device, and a lone wave issues fp32 work four
    * times as fast as fp64: with the early iterations on the fp32 record (MpcParams.f64_f32_start; every solve still finished
-   * by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes 0.54 ms instead of 0.70 ms.  Off by default: the
-   * single-phase solve is the one that matches the oracle on every instance, hard ones included (include/mpc_amd.h). */
+   * by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes 0.54 ms instead of 0.70 ms -- unless its
+   * hand-over is not clean (hard instances), in which case the solve starts again in fp64 and takes longer than the single-phase
+   * one.  Off by default: the single-phase solve is the reference behaviour (include/mpc_amd.h). */
   inline static int fp32Start = 0;
 
   /* Config::load(fileName), Config.cpp:31-87 (parsing and unit conversion live behind the C ABI) */

@@ -543,5 +543,10 @@ pc)   # mixed precision with the clean-hand-over rule: the fp32 phase's iteratio
   done
   unset MPC_PROMOTE_CAP
   ;;
+ph)   # the headline with the fp32 start under the clean-hand-over rule: its restarted instances as deferred tails
+  run() { tag=$1; shift; timeout -k 10 400 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('   %-28s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s' % ('$tag', r['value']/1e6, r['ms_per_step'], r['mean_iterations'], r['max_iterations'], {k: v for k, v in r['status_counts'].items() if v}))" | tee -a $P; }
+  run head_plain --steps 200
+  for c in 0 6 8 10 12; do for nfl in 3 4; do run head_f32s_c${c}_i$nfl --steps 1000 --f64-f32-start --inflight $nfl --tail-cut $c --tail-ring 64; done; done
+  ;;
 esac
 echo done | tee -a $P
