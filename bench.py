@@ -331,7 +331,7 @@ LEGS = {
     "headline_f32_start": ("the headline workload (configs[2]) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above 2e-5) on the fp32 "
                            "record, every instance finished by the fp64 solver to the same tol and polish (a hand-over that is not clean -- fp32 allowance of 16 iterations used up, line search out of single "
                            "precision -- sends the instance to the fp64 solver from the start point); four batches in flight",
-                           dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=3, steps=60, f32_start=True,
+                           dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, steps=100, f32_start=True,
                                 note="1.12x the plain fp64 solve on the same box (58.2 vs 51.9 M solves/s), below the 1.15x set for making it the default, and slower than it on "
                                      "SURVEY's unfiltered population: opt-in (DESIGN.md section 6f); parity tests pass at the same 1e-6 with it forced on (MPC_MIXED=1)")),
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
