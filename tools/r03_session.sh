@@ -131,7 +131,7 @@ p)   # parity of the fp64 solve with its early iterations on the fp32 record (MP
   ;;
 g)   # profiles: the default headline, then the same with its early iterations on the fp32 record (A/B on one box)
   SKIP_TESTS=1 bash tools/gpu_round.sh r03
-  SKIP_TESTS=1 BENCH_ARGS="--f64-f32-start --inflight 3" bash tools/gpu_round.sh r03fs
+  SKIP_TESTS=1 BENCH_ARGS="--f64-f32-start --inflight 4" bash tools/gpu_round.sh r03fs
   ;;
 s)   # the soak tests at full size (every instance against the oracle on the box's cores)
   MPC_SOAK=1 timeout -k 10 1100 python -m pytest tests/test_soak.py -m gpu -q -s > $OUT/r03s_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r03s_pytest.log
