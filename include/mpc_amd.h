@@ -157,12 +157,12 @@ typedef struct MpcParams {
    * them (launches of at least 8 192 instances, single-lane arithmetic unchanged: results are bitwise the same).
    * Default 2; 0 = off. */
   int32_t lane_compact;
-  /* Mixed precision, heavy-tailed workloads (weight sweeps: some instances spend the whole 40-iteration allowance of the fp32
-   * phase while most are handed over after 8-12).  With f32_phase_refill = 1 a lane of the fp32 phase hands its promoted
-   * iterate over through a buffer of its own instead of keeping it in its workspace column, so the lane is free: it takes
-   * further instances while the launch has any, and its column is there for lane compaction.  Same results bit for bit.
-   * Measured: +12-22 % on the weight sweeps of configs[4], -6...-15 % where every instance needs about the same number of
-   * iterations (the copy, and late refills that prolong a wave for a few lanes).  Default 0. */
+  /* Mixed precision, heavy-tailed workloads (weight sweeps: some instances spend the whole allowance of the fp32 phase
+   * while most are handed over after 8-12 iterations).  With f32_phase_refill = 1 a lane of the fp32 phase hands its
+   * instance over through a buffer of its own instead of keeping the iterate in its workspace column, so the lane is
+   * free: it takes further instances while the launch has any, and its column is there for lane compaction.  Same
+   * results bit for bit.  Measured: +12-20 % on the weight sweeps of configs[4], -6...-15 % where every instance needs
+   * about the same number of iterations (the copy, and late refills that prolong a wave for a few lanes).  Default 0. */
   int32_t f32_phase_refill;
   double reserved_d;
 } MpcParams;
