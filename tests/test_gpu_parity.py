@@ -560,6 +560,23 @@ def test_f32_phase_refill_is_bitwise_identical(pkg, golden_dir, waypoints, torch
         for key in ("out", "traj", "status", "iters"):
             assert np.array_equal(r1[key], r0[key]), (N, prec, f32s, cut, key)
         assert (r0["status"] == 0).mean() > 0.99
+    # both switches (and lane compaction) may change on a live handle: the buffer is allocated when it is first wanted
+    q = params.copy(); q.precision = pkg.PRECISION_F32
+    B = 8192 + 3
+    b = pkg.scenarios.lake_track_batch(B, q, waypoints, seed=95)
+    w = pkg.scenarios.weight_sweep(B, q, seed=96, velocity_weights=(0.0, 1.0, 100.0))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=torch.float32)
+    with pkg.BatchedMPC(q, B, device=0) as mpc:
+        seen = []
+        for refill, compact in ((0, 2), (1, 2), (1, 0), (0, 0), (1, 3)):
+            q2 = q.copy(); q2.f32_phase_refill = refill; q2.lane_compact = compact
+            mpc.set_params(q2)
+            r = mpc.solve_torch(t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]), weights=t(w), want_traj=True)
+            torch.cuda.synchronize()
+            seen.append({k: v.cpu().numpy() for k, v in r.items()})
+        for r in seen[1:]:
+            for key in ("out", "traj", "status", "iters"):
+                assert np.array_equal(r[key], seen[0][key]), key
 
 
 def test_tile_pool_is_bitwise_identical_and_used(pkg, golden_dir, waypoints, torch_dev):
