@@ -7,20 +7,20 @@
 
 A "step" is one pass of the hot path (the batched replacement of MPC::solve(), src/control/MPC.cpp:183-325)
 over one batch of synthetic inputs that are ALREADY RESIDENT IN HBM.  Default workload at every N: BASELINE.json
-configs[2] per GPU -- 65 536 lake-track states with 100 ms latency compensation, N=10, dt=0.1,
-config-fast.json, fp64, trajectories requested -- i.e. weak scaling: each rank solves its own 65 536
-instances (different PRNG streams), and every batch's per-instance results are gathered with a single
-all_gather_into_tensor (RCCL) inside the timed region.  Rank 0 prints ONE JSON line.
+configs[2] per GPU -- 65 536 lake-track states with 100 ms latency compensation, N=10, dt=0.1, config-fast.json, fp64,
+trajectories requested, drawn as SURVEY.md section 8d says (rejecting only a compensated speed above Config::maxSpeed:
+`--population survey`) -- i.e. weak scaling: each rank solves its own 65 536 instances (different PRNG streams), and every
+batch's per-instance results are gathered to rank 0 (RCCL).  Rank 0 prints ONE JSON line of at most 2 KB on stdout; everything
+measured (every leg in full) goes to bench_full.json beside this file and to stderr.
 
-Other BASELINE.json configurations through flags (same kernels, parity-tested in tests/):
-    configs[3]  --N 25 --dt 0.05 --config config-stable.json --scaling strong --global-batch 262144 --inflight 4
-    configs[4]  --weights-sweep --precision f32 --no-traj --scaling strong --global-batch 1048576 --inflight 8
-(heavy-tailed iteration counts: a launch lasts as long as its slowest instance, so more batches in flight pay there)
-
-Steps are pipelined the way a serving loop would run them: `--inflight` (default 2) handles on separate streams,
-so the next batch's waves take the SIMDs that the previous launch frees in its tail, and the gather of batch i
-overlaps the solve of batch i+1 (sharding.PackedGather).  All K steps, solves and gathers, complete inside the
-timed region (barrier + synchronize on both sides).
+What is timed.  Steps are pipelined the way a serving loop runs them: `--inflight` handles on separate streams, stragglers
+deferred to the handles' tail slices (MpcParams.tail_cut), results gathered once a batch is final.  A batch of the survey
+population is final 50-150 ms after its launch (its slowest instance runs to the iteration cap), a hundred batch periods.
+So `value` is measured in a PRIMED pipeline: batches are issued continuously; the clock starts when the W-th batch has become
+final (in issue order) and stops when K more have -- every one of those K batches final, stragglers and gather included,
+inside the clock, with later batches being issued behind them the whole time -- and the rate no longer depends on K.  The same
+K batches timed from an empty device to an empty device (barrier + synchronize on both sides, nothing issued behind them) are
+`strict_value`: that number carries the whole latency of the last batch and is a function of K.
 
 roofline: bound "hbm" with ALGORITHMIC bytes per solve (fp64 336 B = in 104 + out 72 +
 trajectory 160; fp32 weight sweep 136 B) x solves per launch / the solve kernel's average launch duration measured
@@ -29,8 +29,10 @@ live with HIP events on the launch stream.  `traffic` is what the kernel really 
 summary of the same workload (profiles/), never measured in this run -- `traffic_source` says so.  The path is
 VALU/latency bound by its algorithmic bytes, so `frac` is tiny by construction; `valu_frac` prices the timed region
 against the vector peak of the dtype (78.6 TFLOP/s fp64, 157.3 fp32) with the flop count of section 8d.
-cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port") on a bounded sample of the same batch: one thread
-(the way the reference runs), and all host cores of this box's share (`cpu_baseline_all_cores`).
+cpu_baseline: the oracle (oracle/mpc_oracle.c, kind "port": dense IPOPT-style interior point) on a bounded sample of the same
+batch, one thread (the way the reference runs).  cpu_baseline_same_algorithm: the CPU build of the device solver's own header
+(tests/host_twin: the same Riccati interior point, scalar C++) on every core of this box's share -- "CPU twin, not IPOPT"
+(SURVEY.md section 8d); both are baselines only, never the product path.
 host_path: the same batch through mpc_solve_batch_host (pageable host arrays -> one H2D, solve, one D2H), and the
 latency of a B = 1 solve, which is what the reference's MPC::solve() drop-in does per telemetry message.
 """
@@ -205,15 +207,18 @@ class _NullCtx:
 
 
 class Pipeline:
-    """One workload kept `nfl` batches in flight the way a serving loop would run it: `nfl` handles on `nfl` streams, results
-    written straight into the packed buffers of sharding.PackedGather, the path's one collective issued per batch.  With
-    deferred tails (tail_cut > 0) a batch's stragglers are finished by its handle's tail launches while later batches run;
-    the batch is gathered -- on a stream of its own, behind the tail's event -- once it is final, and drain() completes
-    everything that is outstanding (the timed region ends after drain())."""
+    """One workload kept in flight the way a serving loop runs it: `nfl` handles on `nfl` streams, results written straight into
+    the packed buffers of sharding.PackedGather, the path's one collective issued when a batch is FINAL.  With deferred tails
+    (tail_cut != 0) a batch's stragglers are finished by its handle's tail slices while later batches run.  Nothing here blocks
+    the host: issue() starts the next batch if a buffer set and a launch slot are free, progress() asks the handles which
+    batches have become final (mpc_tail_poll: that call is also what starts the tail slices) and hands them to the gather, in
+    issue order.  final_upto counts the batches that are final in issue order; marks[n] is the host time at which it reached n."""
 
-    def __init__(self, pkg, torch, params, B, tensors, d_w, want_traj, nfl, dev, local_rank, dist, args, stub=None, tail_cut=0, tail_ring=16):
+    def __init__(self, pkg, torch, params, B, tensors, d_w, want_traj, nfl, dev, local_rank, dist, args, stub=None, tail_cut=0, tail_ring=128,
+                 outstanding=0, depth=2):
+        import collections
         self.torch, self.pkg, self.B, self.nfl, self.dev, self.stub = torch, pkg, B, max(1, nfl), dev, stub
-        self.tensors, self.d_w = tensors, d_w
+        self.tensors, self.d_w, self.depth = tensors, d_w, max(1, depth)
         self.tail = int(tail_cut) if stub is None else 0
         p = params.copy()
         p.tail_cut = self.tail
@@ -221,14 +226,14 @@ class Pipeline:
         self.params = p
         make = (lambda: stub.BatchedMPC(p, B)) if stub else (lambda: pkg.BatchedMPC(p, B, device=local_rank))
         self.mpcs = [make() for _ in range(self.nfl)]
-        self.ring = int(tail_ring) if self.tail else 0
-        # buffer sets: one per batch that may be outstanding (in flight, or waiting for its tail and its gather)
+        # buffer sets: one per batch that may be outstanding (launched, or waiting for its stragglers, or for its gather)
         g = max(1, int(getattr(args, "gather_group", 1) or 1)) if dist is not None else 1
-        n_slots = max(2, self.nfl, 2 * g) if not self.tail else max(self.nfl * (self.ring + 1), 2 * g)
+        n_slots = max(2 * g, 2 * self.nfl * self.depth) if not self.tail else max(int(outstanding) or self.nfl * int(tail_ring), 2 * g)
         tdt = torch.float32 if p.precision == pkg.PRECISION_F32 else torch.float64
         self.pg = pkg.sharding.PackedGather(B, p.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
                                             slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather == "root", gather_traj=not args.gather_results_only,
                                             batches_per_collective=g)
+        self.nslots = self.pg.slots
         self.streams, self.gstream = None, None
         if stub is None:
             torch.cuda.synchronize(dev)
@@ -236,71 +241,130 @@ class Pipeline:
             # batch's solve become ready together, the solve's waves are placed first.
             self.streams = [torch.cuda.Stream(device=dev, priority=0 if args.no_priority_stream else -1) for _ in range(self.nfl)]
             self.gstream = torch.cuda.Stream(device=dev)
-        self.nstep = 0
-        self.owner = [None] * self.pg.slots     # (handle, batch id) whose results sit in the slot
-        self.waiting = []                       # batches issued, not yet handed to the gather: (slot, handle, batch id)
-        self.lag = self.nfl * max(1, self.ring - 2)
+        self.n_issued, self.final_upto = 0, 0
+        self.recs = collections.deque()          # issued, not yet final: [n, handle, batch id, slot, launch event]
+        self.launches = collections.deque()      # launch events of the batches whose own launch may still be running
+        self.timing = collections.deque(maxlen=4096)   # (n, e0, e1): HIP events around each launch, on its stream
+        self.marks = {}
+        self.want_marks = set()
+        self.time_events = stub is None
 
     def _ctx(self, stream):
         return self.torch.cuda.stream(stream) if self.stub is None else _NullCtx()
 
-    def _gather(self, slot, h, bid):
-        with self._ctx(self.gstream):
-            h.tail_stream_wait(bid, self.gstream)          # the batch is final: its own launch and the tail launch that served it
-            self.pg.start(slot)
-
-    def step(self, ev=None):
-        slot = self.nstep % self.pg.slots
-        j = self.nstep % self.nfl
+    def issue(self):
+        """Starts batch number n_issued if its buffer set is free and fewer than nfl x depth launches are unfinished."""
+        n = self.n_issued
+        if n - self.nslots >= self.final_upto:
+            return False                                    # the batch that used this buffer set last is not final yet
+        while self.launches and self.launches[0].query():
+            self.launches.popleft()
+        if len(self.launches) >= self.nfl * self.depth:
+            return False
+        slot, j = n % self.nslots, n % self.nfl
         h = self.mpcs[j]
         st = self.streams[j] if self.streams else None
+        ev = None
         with self._ctx(st):
-            self.pg.wait(slot)                              # the gather that last read this buffer set has finished
-            if self.tail and self.owner[slot] is not None:  # ... and so has the tail that last wrote it
-                self.owner[slot][0].tail_stream_wait(self.owner[slot][1], st)
-            if ev is not None:
-                ev[0].record()
+            self.pg.wait(slot)                              # the gather that last read this buffer set has finished (stream-side wait)
+            if self.time_events:
+                e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                e0.record()
             h.solve_torch(*self.tensors, weights=self.d_w, outputs=self.pg.outputs(slot))   # async on this stream
-            if ev is not None:
-                ev[1].record()
-            if not self.tail:
+            if self.time_events:
+                e1.record()
+                self.timing.append((n, e0, e1))
+                ev = e1
+        if ev is not None:
+            self.launches.append(ev)
+        self.recs.append((n, h, h.last_batch_id() if self.tail else 0, slot, ev))
+        self.n_issued += 1
+        return True
+
+    def progress(self):
+        """Batches that have become final, in issue order -> the gather.  Returns how many."""
+        moved = 0
+        while self.recs:
+            n, h, bid, slot, ev = self.recs[0]
+            if self.tail:
+                ok = h.tail_poll(bid)
+            else:
+                ok = True if ev is None else ev.query()
+            if not ok:
+                break
+            with self._ctx(self.gstream):
+                if self.tail:
+                    h.tail_stream_wait(bid, self.gstream)   # final already: orders the gather's stream behind the tail stream
+                elif ev is not None:
+                    self.gstream.wait_event(ev)
                 self.pg.start(slot)                         # the path's only collective
-        if self.tail:
-            bid = h.last_batch_id()
-            self.owner[slot] = (h, bid)
-            self.waiting.append((slot, h, bid))
-            while len(self.waiting) > self.lag:
-                self._gather(*self.waiting.pop(0))
-        self.nstep += 1
+            self.recs.popleft()
+            self.final_upto = n + 1
+            moved += 1
+            if self.final_upto in self.want_marks or not self.want_marks:
+                self.marks[self.final_upto] = time.perf_counter()
+        return moved
+
+    def run_until(self, cond, issue=True):
+        """The serving loop: issue while allowed, collect what has become final, until cond(self)."""
+        idle = 0
+        while not cond(self):
+            did = self.issue() if issue else False
+            did = bool(self.progress()) or did
+            if not did:
+                idle += 1
+                if idle > 64:
+                    time.sleep(20e-6)                       # nothing to do right now: let the GPU get on with it
+            else:
+                idle = 0
 
     def drain(self):
-        while self.waiting:
-            self._gather(*self.waiting.pop(0))
+        """Everything issued so far becomes final and gathered (blocks)."""
         if self.tail:
             for h in self.mpcs:
                 h.tail_wait(0)
+        self.run_until(lambda p: not p.recs, issue=False)
         self.pg.finish()
 
     def last_slot(self):
-        return (self.nstep - 1) % self.pg.slots
+        return (self.n_issued - 1) % self.nslots
+
+    def kernel_ms(self, lo, hi):
+        return [a.elapsed_time(b) for n, a, b in self.timing if lo <= n < hi]
 
     def close(self):
         for h in self.mpcs:
             h.close()
 
 
-def timed_run(torch, pipe, steps, warmup, sync_all, with_events):
-    for _ in range(warmup):
-        pipe.step()
+def timed_run(pipe, steps, warmup, sync_all):
+    """-> dict: `steady_s` = host time between the moment batch number P became final and the moment batch P + steps did (P >=
+    warmup batches final before the clock starts, batches issued behind the timed ones all along: the primed pipeline);
+    `strict_s` = the same number of batches from an empty device to an empty device, nothing issued behind them."""
+    sync_all()
+    prime = max(int(warmup), 2 * pipe.nfl)
+    pipe.want_marks = set()
+    pipe.run_until(lambda p: p.final_upto >= prime)
+    n0 = pipe.final_upto
+    t_a = pipe.marks.get(n0, time.perf_counter())
+    issued_a = pipe.n_issued
+    pipe.run_until(lambda p: p.final_upto >= n0 + steps)
+    n1 = pipe.final_upto
+    t_b = pipe.marks[n1]
+    outstanding = pipe.n_issued - n1
+    steady = {"steady_s": (t_b - t_a) * steps / (n1 - n0), "first_timed_batch": n0, "batches_in_the_window": n1 - n0,
+              "batches_issued_before_the_clock": issued_a, "batches_outstanding_at_the_end": outstanding}
+    kms = pipe.kernel_ms(n0, n1)
     pipe.drain()
     sync_all()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if with_events else None
     t0 = time.perf_counter()
-    for i in range(steps):
-        pipe.step(ev[i] if ev else None)
+    first = pipe.n_issued
+    pipe.run_until(lambda p: p.n_issued >= first + steps)
     pipe.drain()
     sync_all()
-    return time.perf_counter() - t0, ev
+    steady["strict_s"] = time.perf_counter() - t0
+    steady["kernel_ms"] = kms if kms else pipe.kernel_ms(first, first + steps)
+    return steady
 
 
 def summarize(pkg, np, pipe, B, steps, elapsed):
@@ -309,14 +373,16 @@ def summarize(pkg, np, pipe, B, steps, elapsed):
     iters = outs["iters"].cpu().numpy()
     r = {"solves_per_s": B * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "batch": B, "steps": steps,
          "batches_in_flight": pipe.nfl, "tail_cut": pipe.tail,
-         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in range(6)},
+         "status_counts": {pkg.STATUS_NAMES[k]: int((status == k).sum()) for k in sorted(pkg.STATUS_NAMES)},
          "mean_iterations": float(iters.mean()), "max_iterations": int(iters.max())}
     if pipe.tail and pipe.stub is None:
         info = [h.tail_info() for h in pipe.mpcs]
-        r["tails"] = {"tail_launches": sum(i["tail_launches"] for i in info), "batches_deferred": sum(i["batches_deferred"] for i in info),
+        r["tails"] = {"tail_slices": sum(i["tail_launches"] for i in info), "batches_deferred": sum(i["batches_deferred"] for i in info),
                       "ring": info[0]["ring"], "capacity_per_batch": info[0]["capacity_per_batch"],
-                      "waves_per_tail_launch": info[0]["waves_per_tail_launch"], "tail_stream_high_priority": info[0]["tail_stream_high_priority"], "tail_streams_per_handle": info[0]["tail_streams"],
-                      "instances_over_the_cut_in_the_last_batch": int((iters + 2 > pipe.tail).sum())}
+                      "waves_per_slice_max": info[0]["waves_per_tail_launch"], "passes_per_slice": info[0]["passes_per_slice"],
+                      "batches_not_deferred_survivors_full": sum(i["batches_not_deferred_survivors_full"] for i in info),
+                      "tail_cut_in_use": info[0].get("tail_cut_in_use"),
+                      "buffer_sets": pipe.nslots}
     return r, status, iters, outs
 
 

@@ -12,10 +12,10 @@ NCOEF = 5
 NSTATE = 6
 NOUT = 9
 MAX_N = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 PRECISION_F64, PRECISION_F32 = 0, 1
 
-STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric", 5: "pending"}
+STATUS_NAMES = {0: "success", 1: "maxiter", 2: "linesearch", 3: "infeasible", 4: "numeric", 5: "pending", 6: "acceptable"}
 ERR_NAMES = {0: "MPC_OK", -1: "MPC_ERR_INVALID", -2: "MPC_ERR_NO_DEVICE", -3: "MPC_ERR_HIP",
              -4: "MPC_ERR_UNSUPPORTED", -5: "MPC_ERR_IO"}
 
@@ -42,7 +42,10 @@ class MpcParams(C.Structure):
         ("pass_cut_next", C.c_int32 * 3), ("honor_original_bounds", C.c_int32), ("bound_relax_factor", C.c_double),
         ("tail_cut", C.c_int32), ("tail_ring", C.c_int32), ("tail_capacity", C.c_int64),
         ("f32_finish", C.c_int32), ("f64_f32_start", C.c_int32), ("mixed_switch_mu", C.c_double),
-        ("lane_compact", C.c_int32), ("f32_phase_refill", C.c_int32), ("reserved_d", C.c_double),
+        ("lane_compact", C.c_int32), ("f32_phase_refill", C.c_int32), ("acceptable_iter", C.c_int32),
+        ("dual_inf_tol", C.c_double), ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double),
+        ("acceptable_tol", C.c_double), ("acceptable_dual_inf_tol", C.c_double),
+        ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double), ("reserved_d", C.c_double),
     ]
 
     def copy(self):
@@ -59,7 +62,7 @@ class MpcWireTelemetry(C.Structure):
 
 class MpcBatchStats(C.Structure):
     _fields_ = [("batch", C.c_int64), ("n_success", C.c_int64), ("n_maxiter", C.c_int64),
-                ("n_linesearch", C.c_int64), ("n_infeasible", C.c_int64), ("n_numeric", C.c_int64),
+                ("n_linesearch", C.c_int64), ("n_infeasible", C.c_int64), ("n_numeric", C.c_int64), ("n_acceptable", C.c_int64),
                 ("iter_sum", C.c_int64), ("iter_max", C.c_int32), ("n_pending", C.c_int32),
                 ("kernel_ms", C.c_double)]
 
@@ -71,7 +74,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
            "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device",
-           "mpc_last_batch_id", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
+           "mpc_last_batch_id", "mpc_tail_poll", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
 
 _lib = None
 
@@ -132,6 +135,7 @@ def library():
     L.mpc_last_batch_id.argtypes = [C.c_void_p]
     L.mpc_last_batch_id.restype = C.c_int64
     L.mpc_tail_wait.argtypes = [C.c_void_p, C.c_int64]
+    L.mpc_tail_poll.argtypes = [C.c_void_p, C.c_int64]
     L.mpc_tail_stream_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.mpc_tail_flush.argtypes = [C.c_void_p]
     L.mpc_tail_pending.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]

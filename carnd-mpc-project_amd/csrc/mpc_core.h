@@ -1262,6 +1262,23 @@ struct Solver {
     return mpc_max(mpc_max(e.dinf / sd, e.cinf), compl_ / sc);
   }
 
+  /* IPOPT's termination tests (OptimalityErrorConvergenceCheck, defaults of 3.12 that MPC.cpp:160-179 leaves alone): besides
+   * the scaled error E_0 <= tol an iterate must have its UNSCALED dual infeasibility, constraint violation and complementarity
+   * within dual_inf_tol (1) / constr_viol_tol (1e-4) / compl_inf_tol (1e-4) to be converged; with the acceptable_* values in
+   * their place it is ACCEPTABLE.  Unscaled = divided by the objective scaling df (the bound duals and lam live in the scaled
+   * problem); the products slack x dual are positive, so the complementarity at mu = 0 is e.cmax.  The fp32 solver keeps its
+   * own rule (tol_f32 is above these tolerances). */
+  MPC_HD bool converged_at(const EvalR &e, R E0) const {
+    if (!(E0 <= tol)) return false;
+    if (sizeof(R) == 4) return true;
+    return e.dinf <= (R)P.dual_inf_tol * df && e.cinf <= (R)P.constr_viol_tol && e.cmax <= (R)P.compl_inf_tol * df;
+  }
+  MPC_HD bool acceptable_at(const EvalR &e, R E0) const {
+    if (sizeof(R) == 4 || P.acceptable_iter <= 0) return false;
+    return E0 <= (R)P.acceptable_tol && e.dinf <= (R)P.acceptable_dual_inf_tol * df && e.cinf <= (R)P.acceptable_constr_viol_tol &&
+           e.cmax <= (R)P.acceptable_compl_inf_tol * df;
+  }
+
   MPC_HD bool filter_rejects(R th, R ph) const {
     bool r = false;
     r |= (nf > 0) && th >= fth0 && ph >= fph0;
@@ -1369,7 +1386,11 @@ struct Solver {
   enum { kPromoteIterCap = 16 };   /* mixed precision: the fp32 phase's allowance per instance (the bulk hands over after 8-12 iterations); one that uses it up is solved in fp64 from the start point */
   /* state of the interior-point loop (see step()) */
   int phase, iter, n_polish;
+  int acc_count;   /* acceptable iterates in a row (IPOPT's acceptable_iter counter) */
   bool ls_start, tiny;
+  /* set when a line search fails at an almost feasible point (constraint violation <= 1e-2 tol): IPOPT does not start its
+   * restoration phase there ("restoration phase called, but point is almost feasible"), so the stand-in must not restart */
+  bool no_restart;
   /* Mixed precision across phases (MpcParams.f32_finish / f64_f32_start): an fp32 solver with promote_mu > 0 stops being
    * responsible for an instance as soon as its barrier parameter is about to go below promote_mu (or the instance has met
    * tol_f32, or its line search has run out of single precision): step() returns MPC_PROMOTE at a pass boundary, the
@@ -1395,7 +1416,7 @@ struct Solver {
     for (;;) {
       const int r = step();
       if (r == MPC_RUNNING) continue;
-      if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+      if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !no_restart) {
         attempt = 1; it_total += iters;
         start_point();
         begin(false);
@@ -1408,14 +1429,14 @@ struct Solver {
 
   /* The state of an unfinished instance between two passes with phase == PH_DIR (everything else lives in the
    * current iterate slot of the workspace or is recomputed by setup()): 36 values through an accessor a(q). */
-  enum { PARK_N = 36 };
+  enum { PARK_N = 37 };
   template <class A> MPC_HD void park(A a, int attempt, int it_total) const {
     a(0) = mu; a(1) = tau; a(2) = E.theta; a(3) = E.cinf; a(4) = E.f; a(5) = E.L; a(6) = E.dinf; a(7) = E.cmin; a(8) = E.cmax;
     a(9) = E.lsum; a(10) = E.zsum; a(11) = fth0; a(12) = fth1; a(13) = fth2; a(14) = fth3; a(15) = fph0; a(16) = fph1;
     a(17) = fph2; a(18) = fph3; a(19) = theta_max; a(20) = theta_min; a(21) = dw_last;
     a(22) = (R)nf; a(23) = (R)iter; a(24) = (R)n_reg; a(25) = (R)cur; a(26) = E.ok ? R(1.0) : R(0.0);
     a(27) = ls_start ? R(1.0) : R(0.0); a(28) = (R)attempt; a(29) = (R)it_total;
-    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(35) = R(0.0);
+    a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(35) = R(0.0); a(36) = (R)acc_count;
 #if MPC_S0_VARIABLE
     a(33) = p0; a(34) = v0k;
 #else
@@ -1428,7 +1449,7 @@ struct Solver {
     E.lsum = a(9); E.zsum = a(10); fth0 = a(11); fth1 = a(12); fth2 = a(13); fth3 = a(14); fph0 = a(15); fph1 = a(16);
     fph2 = a(17); fph3 = a(18); theta_max = a(19); theta_min = a(20); dw_last = a(21);
     nf = (int)a(22); iter = (int)a(23); n_reg = (int)a(24); cur = (int)a(25); E.ok = a(26) != R(0.0);
-    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32);
+    attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32); acc_count = (int)a(36);
 #if MPC_S0_VARIABLE
     p0 = a(33); v0k = a(34);
 #endif
@@ -1438,7 +1459,7 @@ struct Solver {
   /* after unpark() of an instance that another precision parked with MPC_PROMOTE: evaluate the point as this solver sees it
    * (one trial sweep with alpha = 0), then carry on; theta_max / theta_min stay those of the start point */
   MPC_HD void promoted() {
-    phase = PH_EVAL0; keep_theta = true; ls_start = false; nf = 0; n_polish = 0; out_step = out_prev = IC::huge;
+    phase = PH_EVAL0; keep_theta = true; ls_start = false; nf = 0; n_polish = 0; acc_count = 0; out_step = out_prev = IC::huge;
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
 #if MPC_S0_VARIABLE
     /* psi_0 / v_0 have arrived at their pinned values long before a hand-over (a factor 100 per iteration); the other
@@ -1452,7 +1473,7 @@ struct Solver {
     /* with the least-squares multiplier start the first pass is the LS pass itself: its trial sweep evaluates the
      * start point (primal part unchanged) with the estimated multipliers, so a separate evaluation is only needed
      * when that estimate is rejected or not wanted */
-    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; out_step = out_prev = IC::huge;
+    phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; acc_count = 0; no_restart = false; out_step = out_prev = IC::huge;
 #if MPC_S0_VARIABLE
     p0 = pushed(st[2], yl, yu); v0k = pushed(st[3], vl, vu);
 #endif
@@ -1465,11 +1486,18 @@ struct Solver {
    * usual reason is that the iterate sits on the noise floor of single precision (multipliers of ~1e3 carry 6e-5 of
    * rounding into the dual residual, slacks of a few ulp cannot shrink), so a point whose optimality error is within
    * IPOPT's "acceptable" band -- here 10 x tol, IPOPT's acceptable_tol/tol is 100 -- is returned as solved. */
-  MPC_HD int line_search_failed() const {
+  MPC_HD int line_search_failed() {
     if ((kCanPromote && promote_mu > R(0.0))) { promote_clean = false; return MPC_PROMOTE; }   /* out of step length in single precision */
-    if (sizeof(R) == 4 && kkt_error(E, R(0.0)) <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
+    const R E0 = kkt_error(E, R(0.0));
+    if (sizeof(R) == 4 && E0 <= R(10.0) * tol) return MPC_STATUS_SUCCESS;
     /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
-    if (n_polish > 0 && kkt_error(E, R(0.0)) <= tol) return MPC_STATUS_SUCCESS;
+    if (n_polish > 0 && converged_at(E, E0)) return MPC_STATUS_SUCCESS;
+    /* IPOPT would call its restoration phase now -- unless the point is acceptable ("restoration phase called at acceptable
+     * point": STOP_AT_ACCEPTABLE_POINT), or almost feasible, where it gives up without trying (no_restart).  Not carried: an
+     * acceptable iterate that is no longer the current one (IPOPT keeps a copy and falls back to it; the oracle restates that
+     * and reports it, OrcSolveInfo.acceptable_restored_older -- on none of the populations this build is measured on). */
+    if (acceptable_at(E, E0)) return MPC_STATUS_ACCEPTABLE;
+    if (sizeof(R) == 8 && P.acceptable_iter > 0 && E.cinf <= R(1e-2) * tol) no_restart = true;
     return MPC_STATUS_LINESEARCH;
   }
 
@@ -1495,7 +1523,7 @@ struct Solver {
         /* as far as this precision is asked to go -- or an instance that is taking long: the stragglers (steps of a few per
          * cent against a bound for dozens of iterations) are where the noise of fp32 steps costs most; they go on in fp64 */
         if ((kCanPromote && promote_mu > R(0.0)) && (E0 <= tol || iter >= promote_cap)) { promote_clean = E0 <= tol; return MPC_PROMOTE; }
-        if (E0 <= tol) {
+        if (converged_at(E, E0)) {
           /* IPOPT's own rule stops here.  Termination polish (MpcParams.polish, include/mpc_amd.h): carry on with
            * Newton steps at the final barrier parameter until the outputs (delta_0, a_0) have stopped moving, so
            * that the point returned is the central-path point itself and not whichever iterate crossed tol first
@@ -1504,7 +1532,11 @@ struct Solver {
             return MPC_STATUS_SUCCESS;
           ++n_polish;
           if (mu > mu_floor) { mu = mu_floor; tau = mpc_max(IC::tau_min, R(1.0) - mu); nf = 0; }
-        }
+        } else if (acceptable_at(E, E0)) {
+          /* IPOPT's acceptable-level termination: acceptable_iter (15) acceptable iterates in a row end the solve with
+           * STOP_AT_ACCEPTABLE_POINT (tested before the iteration cap, as IPOPT does) */
+          if (++acc_count >= P.acceptable_iter) return MPC_STATUS_ACCEPTABLE;
+        } else acc_count = 0;
         if (iter >= P.max_iter) return MPC_STATUS_MAXITER;
         /* barrier update, W&B eq. (7) */
         while (kkt_error(E, mu) <= IC::kappa_eps * mu && mu > mu_floor) {
@@ -1596,7 +1628,7 @@ struct Solver {
      * is returned as it is (line_search_failed). */
     if (accepted && n_polish > 0 && !tiny) {
       const R Et = kkt_error(T, R(0.0));
-      if (sizeof(R) == 8) { if (!(Et <= tol)) return MPC_STATUS_SUCCESS; }
+      if (sizeof(R) == 8) { if (!converged_at(T, Et)) return MPC_STATUS_SUCCESS; }
       else if (!(Et <= R(10.0) * tol)) accepted = false;
     }
     if (accepted) {

@@ -56,13 +56,25 @@ constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchroni
 constexpr int64_t kLdsPerCu = 160 * 1024;
 constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
 constexpr int kCounterInts = 16;    /* two counters per phase */
-constexpr int kParkRows = 36;       /* Solver::PARK_N */
+constexpr int kParkRows = 37;       /* Solver::PARK_N */
 constexpr int kFinPromote = -2, kFinScratch = -3;   /* a lane that waits to hand its instance to the fp64 phase (promoted / to be solved from scratch) */
-constexpr int kTailMaxRing = 64;    /* deferred tails: batches whose stragglers may be outstanding at once */
-constexpr int kTailPerLaunch = 16;  /* queue slots one tail launch serves (they travel as kernel arguments) */
-constexpr int kTailMaxStreams = 4;  /* tail launches that may run side by side */
+constexpr int kTailMaxRing = 512;   /* deferred tails: batches whose stragglers may be outstanding at once */
+constexpr int kFreshRing = 8;       /* fresh queues: one per batch between its launch and the tail slice that absorbs its stragglers */
+constexpr int kSliceMaxSrc = 1 + kFreshRing;   /* what one tail slice reads: the survivors of the slice before it + fresh queues */
+constexpr int kSliceRing = 4;       /* slices whose events and result blocks are kept (at most two are in flight) */
 constexpr int kTailInRows = 6 + MPC_NCOEF + 2 + MPC_NW;   /* the inputs of a deferred instance travel with it: 25 rows */
-constexpr int kTailRows = kParkRows + kTailInRows;
+constexpr int kTailMetaRows = 8;    /* ... and where it belongs: instance, slot, batch id, out, traj, status, iters, ldo */
+constexpr int kTailRows = kParkRows + kTailInRows + kTailMetaRows;
+
+/* One queue of deferred instances: the fresh queue a launch hands its stragglers to, or the list of survivors a tail slice
+ * leaves for the next one.  Entry e: column e of `park` ([kTailRows][cap]: Solver::park scalars, the instance's inputs, where
+ * its results go) and lane e % 64 of tile e / 64 of `iter` ([cap / 64][N-1][IT_SZ][64] reals: its current iterate). */
+struct MpcTailQ {
+  int32_t *count;                  /* entries appended so far (may run past cap: min(count, cap) are valid) */
+  int32_t cap;                     /* multiple of 64 */
+  double *park;
+  void *iter;
+};
 
 /*
  * One instance per lane.  Inputs/outputs are [quantity][instance] so that a wave's access to one
@@ -144,10 +156,9 @@ struct MpcPhase {
    * queue -- solver scalars, its inputs and its current iterate are COPIED out, so the lane and the workspace are free at
    * once -- and reported as MPC_STATUS_PENDING; mpc_tail_kernel finishes it from another stream.  A full queue (t_cap) makes
    * the instance finish here after all. */
-  int32_t tail_cut, t_cap;
-  int32_t *t_count, *t_inst;       /* entries of this batch's queue slot: how many, which instance */
-  double *t_park;                  /* [kTailRows][t_cap]: Solver::park scalars, then state 6, coeffs 5, yaw_lo, yaw_hi, weights 12 */
-  void *t_iter;                    /* [t_cap / 64][N-1][IT_SZ][64] reals: the current iterate, tile of 64 entries */
+  int32_t tail_cut, t_slot;        /* t_slot: the batch's slot in the handle's ring (its live-instance counter, its final flag) */
+  int64_t t_batch;                 /* the batch's id */
+  MpcTailQ tq;                     /* the batch's fresh queue */
   unsigned long long *pool_bits;   /* [8][pool_words]: bit set = tile free; nullptr = no pool */
   void *pool_base;                 /* [8][pool_tiles] tiles */
   int32_t pool_tiles, pool_words;  /* per XCD */
@@ -465,28 +476,32 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           attempt = 0; it_total += S.iters;
           S.start_point();
           S.begin(true);
-        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !S.no_restart) {
           /* the stand-in for IPOPT's restoration phase: once more from the start point, zero multipliers */
           attempt = 1; it_total += S.iters;
           S.start_point();
           S.begin(false);
         } else { fin = true; fin_status = r; have = false; }
       } else if (T.tail_cut > 0 && passes >= T.tail_cut && S.phase == SV::PH_DIR && !queue_full) {
-        const int pos = atomicAdd(T.t_count, 1);
-        if (pos >= T.t_cap) queue_full = true;      /* it finishes here, and so does whatever else this lane takes */
+        const int pos = atomicAdd(T.tq.count, 1);
+        if (pos >= T.tq.cap) queue_full = true;     /* it finishes here, and so does whatever else this lane takes */
         else {
-          T.t_inst[pos] = (int32_t)i;
-          double *pk = T.t_park + pos;
-          const int64_t lp = T.t_cap;
+          double *pk = T.tq.park + pos;
+          const int64_t lp = T.tq.cap;
           S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
           pk += kParkRows * lp;
           for (int q = 0; q < 6; q++) pk[q * lp] = (double)state[q * ld + i];
           for (int q = 0; q < MPC_NCOEF; q++) pk[(6 + q) * lp] = (double)coeffs[q * ld + i];
           pk[11 * lp] = (double)yaw_lo[i]; pk[12 * lp] = (double)yaw_hi[i];
           for (int q = 0; q < MPC_NW; q++) pk[(13 + q) * lp] = weights ? (double)weights[q * ld + i] : P.weights[q];
+          pk += kTailInRows * lp;
+          pk[0] = (double)i; pk[lp] = (double)T.t_slot; pk[2 * lp] = (double)T.t_batch;
+          pk[3 * lp] = __longlong_as_double((long long)out); pk[4 * lp] = __longlong_as_double((long long)traj);
+          pk[5 * lp] = __longlong_as_double((long long)status); pk[6 * lp] = __longlong_as_double((long long)iters);
+          pk[7 * lp] = (double)ldo;
           ws.stage_drain();                          /* the trial sweep's stores of this wave have landed */
           const int I = S.cur ? FL::IT1 : FL::IT0, M = P.N - 1;
-          R *dst = (R *)T.t_iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
+          R *dst = (R *)T.tq.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
           for (int k = 0; k < M; ++k)
             for (int f = 0; f < FL::IT_SZ; f++) dst[(k * FL::IT_SZ + f) * 64] = ws.it(k, I, f);
           status[i] = MPC_STATUS_PENDING;
@@ -514,28 +529,32 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
 #endif
 }
 
-/* Deferred tails: finishes the instances that the launches of several batches handed over (MpcPhase.tail_cut).  Same
- * solver, same arithmetic -- the results are bitwise those of an undisturbed launch -- on the handle's tail stream, a few
- * dense waves beside the launches of later batches.  The queue slots of up to kTailPerLaunch batches are served by one launch;
- * a lane takes entries in turn (global counter) until none is left. */
-struct MpcTailSlot {
-  void *out, *traj;                /* the batch's output arrays (as given to mpc_solve_batch_device), leading dimension ldo */
-  int32_t *status, *iters;
-  int64_t ldo;
-  const int32_t *count, *inst;
-  const double *park;
-  const void *iter;
-};
-struct MpcTailArgs {
-  int32_t n_slots, cap;
-  int32_t *take;
-  int32_t refill_min, refill_wait;
-  MpcTailSlot slot[kTailPerLaunch];
+/* Deferred tails: a TAIL SLICE works on everything the launches have handed over (MpcPhase.tail_cut) for a bounded number of
+ * passes.  Same solver, same arithmetic -- the results are bitwise those of an undisturbed launch -- on the handle's tail
+ * stream, a few dense waves beside the launches of later batches.  Its sources are the survivors of the slice before it and
+ * the fresh queues of the batches whose launches have ended since; a lane takes entries in turn, carries each one on, and
+ * when the slice's budget of passes is spent, whatever is still running is parked again (at a pass boundary) in the
+ * survivors' list for the next slice -- so a slice lasts a couple of milliseconds however long the longest chain is, its
+ * waves are dense again at every slice, and a batch is final a slice after its own last straggler is.  Entries nobody
+ * has taken by then are moved over as they are.  An entry for which the survivors' list has no room left stays with its
+ * lane until it is solved (the slice lasts longer; nothing is lost).
+ * Finality: remaining[slot] counts a batch's live stragglers -- the slice that absorbs its fresh queue adds their number,
+ * every finished one subtracts one -- and whoever brings it to zero writes the batch id into final[slot] (the counter cannot
+ * be zero before both have happened: partial sums without the addition are negative, with it positive). */
+struct MpcSliceArgs {
+  int32_t n_src, budget;           /* sources in use; wave passes after which the slice parks what is still running */
+  MpcTailQ src[kSliceMaxSrc];      /* [0]: survivors of the previous slice; [1..]: fresh queues absorbed by this slice */
+  int32_t fresh_slot[kSliceMaxSrc];
+  int64_t fresh_batch[kSliceMaxSrc];
+  MpcTailQ dst;                    /* survivors of this slice */
+  int32_t *take;                   /* work counter over the concatenated sources */
+  int32_t *remaining;              /* [ring] */
+  long long *final_id;             /* [ring] */
 };
 
 template <bool STAGING, class R, int OCC, class RIO = R>
-__global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P, const MpcTailArgs A, R *__restrict__ wsbase,
-                                                               const int64_t tile_reals) {
+__global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcParams P, const MpcSliceArgs A, R *__restrict__ wsbase,
+                                                                     const int64_t tile_reals) {
   extern __shared__ double smem[];
   using WS = mpc::TiledWorkspace<STAGING, R>;
   using SV = mpc::Solver<WS, R>;
@@ -545,73 +564,93 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P
   ws.lane = threadIdx.x;
   ws.lbuf = (typename WS::lreal *)smem;
   SV S(P, ws);
+  const int M = P.N - 1;
   int64_t total = 0;
-  for (int j = 0; j < A.n_slots; j++) { const int c = *A.slot[j].count; total += c < A.cap ? c : A.cap; }
-  int64_t i = 0;
-  int sj = 0;                                      /* the queue slot (= batch) of the instance this lane holds */
+  for (int j = 0; j < A.n_src; j++) { const int c = *A.src[j].count; total += c < A.src[j].cap ? c : A.src[j].cap; }
+  if (blockIdx.x == 0 && threadIdx.x >= 1 && (int)threadIdx.x < A.n_src) {
+    /* absorb a fresh queue: its stragglers now count as live instances of their batch (a batch that deferred nothing is final here) */
+    const int j = threadIdx.x;
+    const int c0 = *A.src[j].count, c = c0 < A.src[j].cap ? c0 : A.src[j].cap;
+    const int old = atomicAdd(A.remaining + A.fresh_slot[j], c);
+    if (old + c == 0) __hip_atomic_store(A.final_id + A.fresh_slot[j], (long long)A.fresh_batch[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const double *pk = nullptr;                      /* the entry this lane holds: its column in the source's rows, the rows' stride */
+  int64_t lp = 0;
   R ylo_user = 0, yhi_user = 0;
   bool have = false, more = true, fin = false;
-  int attempt = 0, it_total = 0, fin_status = 0, waited = 0;
-  const int M = P.N - 1;
+  bool keep = false;                               /* no room in the survivors' list: this lane's instance is solved here */
+  int attempt = 0, it_total = 0, fin_status = 0, wp = 0;
   for (;;) {
-    const int n_wait = MPC_WAVE_COUNT(fin || (!have && more));
-    if (n_wait > 0) {
-      if (!MPC_WAVE_ANY(have) || n_wait >= A.refill_min || waited >= A.refill_wait) {
-        waited = 0;
-        if (fin) {
-          for (int j = 0; j < A.n_slots; j++)        /* uniform j: the slot's pointers come through the scalar unit */
-            if (j == sj) {
-              const MpcTailSlot &D = A.slot[j];
-              RIO *o = (RIO *)D.out + i;
-              RIO *t = D.traj ? (RIO *)D.traj + i : nullptr;
-              const int64_t l = D.ldo;
-              S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, t != nullptr,
-                       ylo_user, yhi_user);
-              D.status[i] = fin_status;
-              if (D.iters) D.iters[i] = S.iters + it_total;
-            }
-          fin = false;
+    const bool spent = wp >= A.budget;
+    if (fin) {
+      const double *pm = pk + (int64_t)(kParkRows + kTailInRows) * lp;
+      const int64_t i = (int64_t)pm[0];
+      const int slot = (int)pm[lp];
+      RIO *o = (RIO *)__double_as_longlong(pm[3 * lp]) + i;
+      RIO *tb = (RIO *)__double_as_longlong(pm[4 * lp]);
+      RIO *t = tb ? tb + i : nullptr;
+      int32_t *st_arr = (int32_t *)__double_as_longlong(pm[5 * lp]), *it_arr = (int32_t *)__double_as_longlong(pm[6 * lp]);
+      const int64_t l = (int64_t)pm[7 * lp];
+      S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, t != nullptr, ylo_user, yhi_user);
+      st_arr[i] = fin_status;
+      if (it_arr) it_arr[i] = S.iters + it_total;
+      const int old = atomicSub(A.remaining + slot, 1);
+      if (old == 1) __hip_atomic_store(A.final_id + slot, (long long)pm[2 * lp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fin = false;
+    }
+    if (!have && more) {
+      int64_t g = (int64_t)atomicAdd(A.take, 1);
+      more = g < total;
+      if (more) {
+        int sj = 0;
+        for (int j = 0; j < A.n_src; j++) {
+          const int c0 = *A.src[j].count, c = c0 < A.src[j].cap ? c0 : A.src[j].cap;
+          if (g >= c && j == sj) { g -= c; sj = j + 1; }
         }
-        if (!have && more) {
-          int64_t g = (int64_t)atomicAdd(A.take, 1);
-          more = g < total;
-          if (more) {
-            sj = 0;
-            for (int j = 0; j < A.n_slots; j++) {
-              const int c0 = *A.slot[j].count, c = c0 < A.cap ? c0 : A.cap;
-              if (g >= c && j == sj) { g -= c; sj = j + 1; }
-            }
-            for (int j = 0; j < A.n_slots; j++)
-              if (j == sj) {
-                const MpcTailSlot &D = A.slot[j];
-                const int pos = (int)g;
-                i = D.inst[pos];
-                const double *pk = D.park + pos;
-                const int64_t lp = A.cap;
-                const double *pin = pk + kParkRows * lp;
-                R st[6], cf[MPC_NCOEF], w[MPC_NW];
+        const R *it_src = nullptr;
+        for (int j = 0; j < A.n_src; j++)
+          if (j == sj) { pk = A.src[j].park + g; lp = A.src[j].cap; it_src = (const R *)A.src[j].iter + (g >> 6) * (int64_t)M * FL::IT_SZ * 64 + (g & 63); }
+        int dpos = -1;
+        if (spent) {                               /* the budget is spent: the entry moves to the next slice as it is, if there is room */
+          dpos = atomicAdd(A.dst.count, 1);
+          if (dpos >= A.dst.cap) { dpos = -1; keep = true; }
+        }
+        if (dpos >= 0) {
+          double *dk = A.dst.park + dpos;
+          const int64_t dl = A.dst.cap;
+          for (int q = 0; q < kTailRows; q++) dk[q * dl] = pk[q * lp];
+          R *it_dst = (R *)A.dst.iter + (int64_t)(dpos >> 6) * M * FL::IT_SZ * 64 + (dpos & 63);
+          for (int k = 0; k < M; ++k) {
+            R rec[FL::IT_SZ];
 #pragma unroll
-                for (int q = 0; q < 6; q++) st[q] = (R)pin[q * lp];
+            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = it_src[(k * FL::IT_SZ + f) * 64];
 #pragma unroll
-                for (int q = 0; q < MPC_NCOEF; q++) cf[q] = (R)pin[(6 + q) * lp];
-#pragma unroll
-                for (int q = 0; q < MPC_NW; q++) w[q] = (R)pin[(13 + q) * lp];
-                ylo_user = (R)pin[11 * lp]; yhi_user = (R)pin[12 * lp];
-                (void)S.setup(st, cf, ylo_user, yhi_user, w, false);
-                S.unpark([pk, lp](int q) -> double { return pk[q * lp]; }, attempt, it_total);
-                const R *src = (const R *)D.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
-                const int I = S.cur ? FL::IT1 : FL::IT0;
-                for (int k = 0; k < M; ++k) {
-                  R rec[FL::IT_SZ];
-#pragma unroll
-                  for (int f = 0; f < FL::IT_SZ; f++) rec[f] = src[(k * FL::IT_SZ + f) * 64];
-                  ws.template store_run<0, FL::IT_SZ>(k, I, rec);
-                }
-                have = true;
-              }
+            for (int f = 0; f < FL::IT_SZ; f++) it_dst[(k * FL::IT_SZ + f) * 64] = rec[f];
           }
+        } else {
+          const double *pin = pk + (int64_t)kParkRows * lp;
+          R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+          for (int q = 0; q < 6; q++) st[q] = (R)pin[q * lp];
+#pragma unroll
+          for (int q = 0; q < MPC_NCOEF; q++) cf[q] = (R)pin[(6 + q) * lp];
+#pragma unroll
+          for (int q = 0; q < MPC_NW; q++) w[q] = (R)pin[(13 + q) * lp];
+          ylo_user = (R)pin[11 * lp]; yhi_user = (R)pin[12 * lp];
+          (void)S.setup(st, cf, ylo_user, yhi_user, w, false);
+          const double *pq = pk;
+          const int64_t lq = lp;
+          S.unpark([pq, lq](int q) -> double { return pq[q * lq]; }, attempt, it_total);
+          const int I = S.cur ? FL::IT1 : FL::IT0;
+          for (int k = 0; k < M; ++k) {
+            R rec[FL::IT_SZ];
+#pragma unroll
+            for (int f = 0; f < FL::IT_SZ; f++) rec[f] = it_src[(k * FL::IT_SZ + f) * 64];
+            ws.template store_run<0, FL::IT_SZ>(k, I, rec);
+          }
+          have = true;
         }
-      } else ++waited;
+      }
     }
     if (!MPC_WAVE_ANY(have || more || fin)) break;
     if (have) {
@@ -621,13 +660,30 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_kernel(const MpcParams P
           attempt = 0; it_total += S.iters;
           S.start_point();
           S.begin(true);
-        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        } else if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !S.no_restart) {
           attempt = 1; it_total += S.iters;
           S.start_point();
           S.begin(false);
-        } else { fin = true; fin_status = r; have = false; }
+        } else { fin = true; fin_status = r; have = false; keep = false; }
+      } else if (spent && !keep && S.phase == SV::PH_DIR) {
+        /* still running when the slice's budget is spent: parked for the next slice (its inputs and destination come along) */
+        const int dpos = atomicAdd(A.dst.count, 1);
+        if (dpos >= A.dst.cap) keep = true;
+        else {
+          double *dk = A.dst.park + dpos;
+          const int64_t dl = A.dst.cap;
+          S.park([dk, dl](int q) -> double & { return dk[q * dl]; }, attempt, it_total);
+          for (int q = kParkRows; q < kTailRows; q++) dk[q * dl] = pk[q * lp];
+          ws.stage_drain();
+          const int I = S.cur ? FL::IT1 : FL::IT0;
+          R *it_dst = (R *)A.dst.iter + (int64_t)(dpos >> 6) * M * FL::IT_SZ * 64 + (dpos & 63);
+          for (int k = 0; k < M; ++k)
+            for (int f = 0; f < FL::IT_SZ; f++) it_dst[(k * FL::IT_SZ + f) * 64] = ws.it(k, I, f);
+          have = false;
+        }
       }
     }
+    ++wp;
   }
 }
 
@@ -731,30 +787,32 @@ __global__ __launch_bounds__(256) void mpc_rollout_step_kernel(int64_t B, int64_
 }
 
 /* Statistics of a batch, accumulated into handle-owned memory right behind the solve (mpc_get_stats never touches
- * the caller's arrays again): acc[0..4] = instances per status code, acc[5] = sum of iterations, acc[6] = max. */
+ * the caller's arrays again): acc[0..4] = instances per status code 0..3 and "any other", acc[5] = sum of iterations,
+ * acc[6] = max, acc[7] = pending, acc[8] = MPC_STATUS_ACCEPTABLE. */
+constexpr int kStatWords = 10;
 __global__ __launch_bounds__(256) void mpc_stats_kernel(int64_t B, const int32_t *__restrict__ status, const int32_t *__restrict__ iters,
                                                         unsigned long long *__restrict__ acc) {
-  __shared__ unsigned int cnt[5];
+  __shared__ unsigned int cnt[6];
   __shared__ unsigned long long isum;
   __shared__ int imax;
-  if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 6) cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) { isum = 0; imax = 0; }
   __syncthreads();
-  unsigned int my[5] = {0, 0, 0, 0, 0}, pend = 0;
+  unsigned int my[6] = {0, 0, 0, 0, 0, 0}, pend = 0;
   unsigned long long ms = 0;
   int mm = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t st = status[i];
     if (st == MPC_STATUS_PENDING) { ++pend; continue; }   /* deferred: counted, its iterations are not final */
-    const int c = (st >= 0 && st < 4) ? st : 4;
+    const int c = st == MPC_STATUS_ACCEPTABLE ? 5 : ((st >= 0 && st < 4) ? st : 4);
 #pragma unroll
-    for (int q = 0; q < 5; q++) my[q] += (c == q);
+    for (int q = 0; q < 6; q++) my[q] += (c == q);
     const int it = iters ? iters[i] : 0;
     ms += (unsigned long long)it;
     mm = it > mm ? it : mm;
   }
 #pragma unroll
-  for (int q = 0; q < 5; q++) if (my[q]) atomicAdd(&cnt[q], my[q]);
+  for (int q = 0; q < 6; q++) if (my[q]) atomicAdd(&cnt[q], my[q]);
   if (ms) atomicAdd(&isum, ms);
   if (mm) atomicMax(&imax, mm);
   if (pend) atomicAdd(&acc[7], (unsigned long long)pend);
@@ -762,6 +820,7 @@ __global__ __launch_bounds__(256) void mpc_stats_kernel(int64_t B, const int32_t
   if (threadIdx.x < 5 && cnt[threadIdx.x]) atomicAdd(&acc[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
   if (threadIdx.x == 5 && isum) atomicAdd(&acc[5], isum);
   if (threadIdx.x == 6 && imax) atomicMax(&acc[6], (unsigned long long)imax);
+  if (threadIdx.x == 7 && cnt[5]) atomicAdd(&acc[8], (unsigned long long)cnt[5]);
 }
 
 __global__ void mpc_debug_math_kernel(int64_t n, const double *x, double *sn, double *cs, double *rc, double *at, double *lg) {
@@ -841,7 +900,7 @@ struct MpcHandle {
    * leading dimension: in = state[6] coeffs[5] ylo yhi weights[12] (25 rows) | out = out[9] traj[2N] | one row holding
    * status and iters (int32 each) -- so a call is one copy in, the launch, one copy out */
   void *d_io = nullptr, *h_io = nullptr;
-  unsigned long long *d_stats = nullptr;   /* [8] statistics of the last batch (mpc_stats_kernel) */
+  unsigned long long *d_stats = nullptr;   /* [kStatWords] statistics of the last batch (mpc_stats_kernel) */
   hipEvent_t ev_stats = nullptr;
   bool have_stats = false;
   double *d_run = nullptr;    /* run(): pre[15] rows */
@@ -869,29 +928,59 @@ struct MpcHandle {
   bool promote_buffer = false, promote_env = false;   /* MpcParams.f32_phase_refill (MPC_PROMOTE_BUFFER in the environment overrides: measurement aid) */
   int32_t *d_list = nullptr;  /* [2][2][io_stride]: instance, source column */
   MpcTilePool *pool = nullptr;   /* MPC_TILE_POOL=1 */
-  /* deferred tails (MpcParams.tail_cut > 0; allocated on first use) */
-  struct TailSlot {
-    int64_t batch_id = 0;        /* the batch whose stragglers sit in this queue slot (0: never used) */
-    int64_t launch = -1;         /* the tail launch that serves it (-1: none yet) */
-    void *out = nullptr, *traj = nullptr; int32_t *status = nullptr, *iters = nullptr; int64_t ldo = 0;
-    hipEvent_t bulk = nullptr;   /* recorded behind the batch's own launch */
+  /* deferred tails (MpcParams.tail_cut > 0; allocated on first use): see "tail slices" below */
+  struct TailSlot {                /* one per batch whose stragglers may be outstanding (ring of tail_ring) */
+    int64_t batch_id = 0;          /* 0: never used */
+    bool final_ = true;
+    int64_t deferred = -1;         /* instances the batch handed over (known once the absorbing slice has completed) */
+    int64_t B = 0;
   };
+  struct FreshQ {                  /* the queue a launch hands its stragglers to, until a slice absorbs it (ring of kFreshRing) */
+    int64_t batch_id = 0;
+    int slot = 0;
+    int state = 0;                 /* 0 free, 1 filled by a launch (bulk recorded), 2 absorbed by slice `slice` */
+    int64_t slice = -1;
+    hipEvent_t bulk = nullptr;
+  };
+  struct BatchRec {                /* the last kBatchRecs solve calls: how mpc_tail_wait resolves an id */
+    int64_t id = 0;
+    int kind = 0;                  /* 0 not deferring: final behind `ev`; 1 deferring: final per its slot */
+    int slot = 0;
+    hipEvent_t ev = nullptr;
+  };
+  static constexpr int kBatchRecs = 1024;
+  struct SliceRes { int32_t src_count[kSliceMaxSrc]; int32_t dst_count; int32_t pad[2]; };
   bool tail_ready = false;
-  bool tail_double = true;     /* the solver of the tail launches: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
-  int tail_ring = 0, tail_waves = 256, tail_priority = 0;
-  int64_t tail_cap = 0, tail_min_batch = 4096;
-  int n_tail_streams = 2;
-  hipStream_t tail_stream[kTailMaxStreams] = {};
-  int64_t stream_launch[kTailMaxStreams] = {-1, -1, -1, -1};   /* the most recent tail launch on each of them */
-  int32_t *d_tcount = nullptr, *d_tinst = nullptr, *d_ttake = nullptr;
-  double *d_tpark = nullptr;
-  void *d_titer = nullptr, *tail_ws = nullptr;
-  size_t titer_slot_bytes = 0;
+  bool tail_double = true;     /* the solver of the tail slices: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
+  int tail_ring = 0, tail_waves = 128, tail_priority = 0, slice_passes = 24;
+  int64_t tail_cap = 0, surv_cap = 0, tail_min_batch = 4096;
+  hipStream_t tail_stream = nullptr;
+  MpcTailQ fq_dev[kFreshRing] = {}, surv_dev[2] = {};   /* device storage of the fresh queues and the two survivor lists */
+  int32_t *d_tcount = nullptr;   /* [kFreshRing + 2 + kSliceRing]: counts of the fresh queues, of the survivor lists, slice work counters */
+  int32_t *d_remaining = nullptr;
+  long long *d_final = nullptr;
+  long long *h_final = nullptr;  /* pinned: [kSliceRing][tail_ring] the final flags as copied behind each slice */
+  SliceRes *h_res = nullptr;     /* pinned: [kSliceRing] */
+  void *tail_ws = nullptr;
   TailSlot tslot[kTailMaxRing];
-  hipEvent_t tail_ev[kTailMaxRing] = {};
+  FreshQ fq[kFreshRing];
+  BatchRec *brec = nullptr;
+  hipEvent_t slice_ev[kSliceRing] = {};
+  int slice_nabs[kSliceRing] = {};            /* fresh queues slice k % kSliceRing absorbed, and which */
+  int slice_abs[kSliceRing][kFreshRing] = {};
+  int64_t n_slice = 0, n_slice_done = 0;      /* slices launched / retired */
+  int64_t surv_last = 0;                      /* survivors the most recent retired slice left */
+  int64_t fresh_avg = 64;                     /* running estimate of a batch's deferred instances (sizes a slice's grid) */
+  int64_t n_not_final = 0;                    /* deferring batches not yet known to be final */
+  int64_t n_throttled = 0;                    /* batches that ran without deferral because the survivors' list was filling up */
+  /* MpcParams.tail_cut = MPC_TAIL_AUTO: the cut follows the share of a batch that ends up deferred (a running mean over the
+   * batches retired so far, in 1/65536): above auto_hi the cut goes up a pass, below auto_lo down, at most every fourth batch.
+   * (The arithmetic of an instance does not depend on where it is carried on, so the cut changes timing only.) */
+  int auto_cut = 20, auto_since = 0;
+  int64_t auto_share = -1;
+  int64_t auto_lo = 262, auto_hi = 983;       /* 0.4 % and 1.5 % of a batch; MPC_TAIL_AUTO_LO / _HI in 1/65536 */
   int64_t batch_seq = 0;         /* id of the most recent batch (every solve call counts) */
-  int64_t n_deferred = 0;        /* deferred batches so far: batch k of them uses queue slot k % tail_ring */
-  int64_t n_tail_launch = 0;
+  int64_t n_deferred = 0;        /* deferring batches so far: batch k of them uses slot k % tail_ring and fresh queue k % kFreshRing */
   double *d_tel = nullptr;       /* mpc_telemetry_batch_host: device staging, grown on demand */
   size_t tel_bytes = 0;
   /* last call */
@@ -937,7 +1026,7 @@ static int validate_params(const MpcParams *p) {
   if (p->precision != MPC_PRECISION_F64 && p->precision != MPC_PRECISION_F32) { g_last_error = "unknown precision"; return MPC_ERR_INVALID; }
   if (p->precision == MPC_PRECISION_F32 && !(p->tol_f32 >= 1e-5)) { g_last_error = "tol_f32 below 1e-5 is beyond single precision"; return MPC_ERR_INVALID; }
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
-  if (p->tail_cut < 0 || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
+  if (p->tail_cut < MPC_TAIL_AUTO || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
   if (p->f64_f32_start < 0 || p->f64_f32_start > MPC_F32_START_AUTO) { g_last_error = "f64_f32_start must be 0 (off), 1 (on) or 2 (auto)"; return MPC_ERR_INVALID; }
   if (p->lane_compact < 0 || p->lane_compact > 7) { g_last_error = "lane_compact must be 0 (off) .. 7"; return MPC_ERR_INVALID; }
   return MPC_OK;
@@ -1051,7 +1140,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_counter, kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void **)&h->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_stats, kStatWords * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   set_cuts(h, p);
   if (const char *ep = getenv("MPC_TILE_POOL")) {
@@ -1085,7 +1174,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   return MPC_OK;
 }
 
-static int tail_flush(MpcHandle *h, int si);
+static int tail_drain(MpcHandle *h);
 
 extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
@@ -1099,12 +1188,11 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
     g_last_error = "tail_ring and tail_capacity cannot change once the tail queue exists"; return MPC_ERR_INVALID;
   }
   if (h->tail_ready) {
-    /* stragglers of earlier batches are finished under the parameters their batch was issued with: every tail launch
-     * takes the handle's parameters by value when it goes out, so what is still queued goes out, and completes, first */
+    /* stragglers of earlier batches are finished under the parameters their batch was issued with: every tail slice
+     * takes the handle's parameters by value when it goes out, so what is still queued is finished first */
     MPC_ON_DEVICE(h);
-    const int rf = tail_flush(h, -1);
+    const int rf = tail_drain(h);
     if (rf != MPC_OK) return rf;
-    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
   }
   h->params = *p;
   set_cuts(h, p);
@@ -1134,14 +1222,24 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_list) (void)hipFree(h->d_list);
   if (h->d_piter) (void)hipFree(h->d_piter);
   if (h->d_tel) (void)hipFree(h->d_tel);
-  for (int q = 0; q < kTailMaxStreams; q++) if (h->tail_stream[q]) (void)hipStreamSynchronize(h->tail_stream[q]);
-  for (void *q : {(void *)h->d_tcount, (void *)h->d_tinst, (void *)h->d_ttake, (void *)h->d_tpark, h->d_titer, h->tail_ws})
+  if (h->tail_ready) (void)tail_drain(h);         /* stragglers still queued are finished: their batches' arrays may be read afterwards */
+  if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
+  for (void *q : {(void *)h->d_tcount, (void *)h->d_remaining, (void *)h->d_final, h->tail_ws, (void *)h->surv_dev[0].park, h->surv_dev[0].iter,
+                  (void *)h->surv_dev[1].park, h->surv_dev[1].iter})
     if (q) (void)hipFree(q);
-  for (int q = 0; q < kTailMaxRing; q++) {
-    if (h->tslot[q].bulk) (void)hipEventDestroy(h->tslot[q].bulk);
-    if (h->tail_ev[q]) (void)hipEventDestroy(h->tail_ev[q]);
+  for (int q = 0; q < kFreshRing; q++) {
+    if (h->fq_dev[q].park) (void)hipFree(h->fq_dev[q].park);
+    if (h->fq_dev[q].iter) (void)hipFree(h->fq_dev[q].iter);
+    if (h->fq[q].bulk) (void)hipEventDestroy(h->fq[q].bulk);
   }
-  for (int q = 0; q < kTailMaxStreams; q++) if (h->tail_stream[q]) (void)hipStreamDestroy(h->tail_stream[q]);
+  if (h->h_final) (void)hipHostFree(h->h_final);
+  if (h->h_res) (void)hipHostFree(h->h_res);
+  for (int q = 0; q < kSliceRing; q++) if (h->slice_ev[q]) (void)hipEventDestroy(h->slice_ev[q]);
+  if (h->brec) {
+    for (int q = 0; q < MpcHandle::kBatchRecs; q++) if (h->brec[q].ev) (void)hipEventDestroy(h->brec[q].ev);
+    delete[] h->brec;
+  }
+  if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1150,7 +1248,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
 
 /* statistics of (status, iters) into the handle's own counters, behind whatever wrote them on stream s */
 static int record_stats(MpcHandle *h, int64_t B, const int32_t *status, const int32_t *iters, hipStream_t s) {
-  MPC_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), s));
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, kStatWords * sizeof(unsigned long long), s));
   unsigned grid = (unsigned)((B + 256 * 8 - 1) / (256 * 8));
   if (grid > 256) grid = 256;
   hipLaunchKernelGGL(mpc_stats_kernel, dim3(grid), dim3(256), 0, s, B, status, iters, h->d_stats);
@@ -1180,7 +1278,23 @@ static int launch_lds(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R 
   }
 }
 
-/* ---- deferred tails: queue storage, the tail launch, waiting for a batch ---- */
+/* ---- deferred tails: queues, tail slices, the pump, waiting for a batch -------------------------------------------------
+ * A launch with a cut hands its stragglers to the FRESH QUEUE of its batch.  They are carried on by TAIL SLICES
+ * (mpc_tail_slice_kernel) on the handle's own high-priority stream: slice k reads the survivors slice k-1 left and the fresh
+ * queues of the batches whose launches have ended since, works for a bounded number of passes, and leaves its own survivors.
+ * Slices are started by the PUMP (tail_pump), which every solve call and every wait runs: it retires the slices that have
+ * completed (reads their counters and the final flags), and starts the next one while at most two are in flight.  Nothing
+ * runs between calls: a batch is final when mpc_tail_wait / mpc_tail_poll / mpc_tail_stream_wait says so. */
+static int tail_alloc_queue(MpcHandle *h, MpcTailQ &Q, int64_t cap, int32_t *count) {
+  const bool f32 = !h->tail_double;
+  const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
+  const size_t it_sz = f32 ? (size_t)mpc::Fields<float>::IT_SZ : (size_t)mpc::Fields<double>::IT_SZ;
+  Q.cap = (int32_t)cap; Q.count = count;
+  if (!Q.park) MPC_HIP_CHECK(hipMalloc((void **)&Q.park, sizeof(double) * (size_t)kTailRows * (size_t)cap));
+  if (!Q.iter) MPC_HIP_CHECK(hipMalloc(&Q.iter, (size_t)(cap / 64) * (size_t)(h->params.N - 1) * it_sz * 64 * real_bytes));
+  return MPC_OK;
+}
+
 static int tail_prepare(MpcHandle *h) {
   if (h->tail_ready) return MPC_OK;
   const MpcParams &P = h->params;
@@ -1189,126 +1303,216 @@ static int tail_prepare(MpcHandle *h) {
   const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
   const int64_t tail_stride = f32 ? h->ws_stride_f32 : h->ws_stride_f64;
   h->tail_ring = P.tail_ring < 2 ? 2 : (P.tail_ring > kTailMaxRing ? kTailMaxRing : P.tail_ring);
-  int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 8;
+  int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 16;
   if (cap < 256) cap = 256;
   if (cap > h->io_stride) cap = h->io_stride;
   h->tail_cap = (cap + 63) / 64 * 64;
+  /* survivors: everything the outstanding batches may have alive at once.  A slice that finds the list full keeps the
+   * instance until it is solved, and the solve calls stop deferring while the list is more than half full. */
+  int64_t sc = 4 * h->tail_cap;
+  if (sc < 16384) sc = 16384;
+  if (const char *e = getenv("MPC_TAIL_SURVIVORS")) { sc = atoll(e); if (sc < 64) sc = 64; }
+  h->surv_cap = (sc + 63) / 64 * 64;
   if (const char *e = getenv("MPC_TAIL_WAVES")) { h->tail_waves = atoi(e); if (h->tail_waves < 1) h->tail_waves = 1; }
   if (const char *e = getenv("MPC_TAIL_MIN_BATCH")) { h->tail_min_batch = atoll(e); if (h->tail_min_batch < 1) h->tail_min_batch = 1; }
-  const int64_t max_tail_waves = (h->tail_cap / 64) * h->tail_ring;
-  if (h->tail_waves > max_tail_waves) h->tail_waves = (int)max_tail_waves;
-  /* The tail stream's priority.  Stragglers are few waves with long serial chains: they should start as soon as a
-   * SIMD is free, so the default is the HIGH priority (MPC_TAIL_PRIORITY=low|normal|high to measure the others). */
+  if (const char *e = getenv("MPC_SLICE_PASSES")) { h->slice_passes = atoi(e); if (h->slice_passes < 1) h->slice_passes = 1; }
+  if (const char *e = getenv("MPC_TAIL_AUTO_LO")) h->auto_lo = atoll(e);
+  if (const char *e = getenv("MPC_TAIL_AUTO_HI")) h->auto_hi = atoll(e);
+  if (const char *e = getenv("MPC_TAIL_AUTO_START")) { h->auto_cut = atoi(e); if (h->auto_cut < 8) h->auto_cut = 8; }
+  /* The tail stream's priority.  Stragglers are few waves with long chains: they should start as soon as a SIMD is free,
+   * so the default is the HIGH priority (MPC_TAIL_PRIORITY=low|normal|high to measure the others). */
   int lo = 0, hi = 0;
   MPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      /* lo = least, hi = greatest priority (numerically smaller) */
   int prio = hi;
   if (const char *e = getenv("MPC_TAIL_PRIORITY")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "normal") ? 0 : hi);
   h->tail_priority = prio;
-  /* Tail launches side by side: a launch lasts as long as its slowest straggler (up to 2 x max_iter iterations with the
-   * restart: tens of milliseconds), and a batch is final only when the launch that serves it is; with one launch at a time a
-   * batch waits for the running launch AND its own, with S of them for 1/S of the running one. */
-  if (const char *e = getenv("MPC_TAIL_STREAMS")) h->n_tail_streams = atoi(e);
-  if (h->n_tail_streams < 1) h->n_tail_streams = 1;
-  if (h->n_tail_streams > kTailMaxStreams) h->n_tail_streams = kTailMaxStreams;
-  for (int q = 0; q < h->n_tail_streams; q++)
-    if (!h->tail_stream[q]) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream[q], hipStreamNonBlocking, prio));
-  const int64_t K = h->tail_ring, cp = h->tail_cap;
-  const int M = P.N - 1;
-  const size_t it_sz = f32 ? (size_t)mpc::Fields<float>::IT_SZ : (size_t)mpc::Fields<double>::IT_SZ;
-  h->titer_slot_bytes = (size_t)(cp / 64) * M * it_sz * 64 * real_bytes;
-  if (!h->d_tcount) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * kTailMaxRing));
-  MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * kTailMaxRing));
-  if (!h->d_ttake) MPC_HIP_CHECK(hipMalloc((void **)&h->d_ttake, sizeof(int32_t) * kTailMaxRing));
-  if (!h->d_tinst) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tinst, sizeof(int32_t) * K * cp));
-  if (!h->d_tpark) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tpark, sizeof(double) * K * kTailRows * cp));
-  if (!h->d_titer) MPC_HIP_CHECK(hipMalloc((void **)&h->d_titer, h->titer_slot_bytes * K));
-  if (!h->tail_ws) MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes * (size_t)h->n_tail_streams));
-  for (int q = 0; q < kTailMaxRing; q++) {
-    if (!h->tslot[q].bulk) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tslot[q].bulk, hipEventDisableTiming));
-    if (!h->tail_ev[q]) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->tail_ev[q], hipEventDisableTiming));
+  if (!h->tail_stream) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, prio));
+  const int n_counts = kFreshRing + 2 + kSliceRing;
+  if (!h->d_tcount) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * n_counts));
+  MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * n_counts));
+  if (!h->d_remaining) MPC_HIP_CHECK(hipMalloc((void **)&h->d_remaining, sizeof(int32_t) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMemset(h->d_remaining, 0, sizeof(int32_t) * kTailMaxRing));
+  if (!h->d_final) MPC_HIP_CHECK(hipMalloc((void **)&h->d_final, sizeof(long long) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMemset(h->d_final, 0, sizeof(long long) * kTailMaxRing));
+  if (!h->h_final) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_final, sizeof(long long) * kTailMaxRing * kSliceRing, hipHostMallocDefault));
+  if (!h->h_res) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_res, sizeof(MpcHandle::SliceRes) * kSliceRing, hipHostMallocDefault));
+  memset(h->h_final, 0, sizeof(long long) * kTailMaxRing * kSliceRing);
+  memset(h->h_res, 0, sizeof(MpcHandle::SliceRes) * kSliceRing);
+  for (int q = 0; q < kFreshRing; q++) {
+    const int rc = tail_alloc_queue(h, h->fq_dev[q], h->tail_cap, h->d_tcount + q);
+    if (rc != MPC_OK) return rc;
+    if (!h->fq[q].bulk) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->fq[q].bulk, hipEventDisableTiming));
   }
+  for (int q = 0; q < 2; q++) {
+    const int rc = tail_alloc_queue(h, h->surv_dev[q], h->surv_cap, h->d_tcount + kFreshRing + q);
+    if (rc != MPC_OK) return rc;
+  }
+  if (!h->tail_ws) MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes));
+  for (int q = 0; q < kSliceRing; q++)
+    if (!h->slice_ev[q]) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->slice_ev[q], hipEventDisableTiming));
   h->tail_ready = true;
   return MPC_OK;
 }
 
-/* Tail launches for every deferred batch that none serves yet (kTailPerLaunch batches per launch), on tail stream `si`
- * (-1: the first idle one, else the one whose launch is the oldest) */
-static int tail_flush(MpcHandle *h, int si) {
-  if (!h->tail_ready) return MPC_OK;
-  int order[kTailMaxRing];
-  int n = 0;
-  for (int q = 0; q < h->tail_ring; q++)
-    if (h->tslot[q].batch_id != 0 && h->tslot[q].launch < 0) order[n++] = q;
-  if (n == 0) return MPC_OK;
-  for (int a = 1; a < n; a++)           /* oldest batch first */
-    for (int b = a; b > 0 && h->tslot[order[b]].batch_id < h->tslot[order[b - 1]].batch_id; b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
-  if (si < 0) {
-    si = 0;
-    for (int q = 0; q < h->n_tail_streams; q++) if (h->stream_launch[q] < h->stream_launch[si]) si = q;
+/* the records of the last solve calls (allocated with the first one) */
+static int batch_rec(MpcHandle *h, int64_t id, MpcHandle::BatchRec **out) {
+  if (!h->brec) h->brec = new MpcHandle::BatchRec[MpcHandle::kBatchRecs];
+  MpcHandle::BatchRec &R = h->brec[id % MpcHandle::kBatchRecs];
+  if (!R.ev) MPC_HIP_CHECK(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+  *out = &R;
+  return MPC_OK;
+}
+
+static int tail_retire(MpcHandle *h, bool block, int *n_retired);
+
+/* Starts tail slice number h->n_slice.  It absorbs every filled fresh queue whose launch has ended (`force`: every filled one --
+ * the slice then waits for those launches on the device). */
+static int tail_launch_slice(MpcHandle *h, bool force) {
+  while (h->n_slice - h->n_slice_done >= kSliceRing - 1) {      /* (the result blocks are a ring: never more than kSliceRing - 1 in flight) */
+    int nr = 0;
+    const int rc = tail_retire(h, true, &nr);
+    if (rc != MPC_OK) return rc;
   }
-  const int64_t cp = h->tail_cap;
+  const int64_t k = h->n_slice;
+  const int kr = (int)(k % kSliceRing);
+  hipStream_t ts = h->tail_stream;
+  MpcSliceArgs A;
+  memset(&A, 0, sizeof(A));
+  A.src[0] = h->surv_dev[k & 1];
+  A.dst = h->surv_dev[(k + 1) & 1];
+  A.n_src = 1;
+  h->slice_nabs[kr] = 0;
+  int64_t est = h->surv_last;
+  /* oldest batch first */
+  for (int step = 0; step < kFreshRing; step++) {
+    int best = -1;
+    for (int q = 0; q < kFreshRing; q++)
+      if (h->fq[q].state == 1 && (best < 0 || h->fq[q].batch_id < h->fq[best].batch_id)) best = q;
+    if (best < 0) break;
+    MpcHandle::FreshQ &F = h->fq[best];
+    if (!force) {
+      const hipError_t e = hipEventQuery(F.bulk);
+      if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }      /* (launches of one handle end in the order they were issued, or nearly) */
+      if (e != hipSuccess) { g_last_error = std::string("hipEventQuery: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
+    }
+    MPC_HIP_CHECK(hipStreamWaitEvent(ts, F.bulk, 0));
+    const int j = A.n_src++;
+    A.src[j] = h->fq_dev[best]; A.fresh_slot[j] = F.slot; A.fresh_batch[j] = F.batch_id;
+    F.state = 2; F.slice = k;
+    h->slice_abs[kr][h->slice_nabs[kr]++] = best;
+    est += h->fresh_avg;
+  }
+  A.budget = h->slice_passes;
+  A.take = h->d_tcount + kFreshRing + 2 + kr;
+  A.remaining = h->d_remaining; A.final_id = h->d_final;
+  MPC_HIP_CHECK(hipMemsetAsync(A.take, 0, sizeof(int32_t), ts));
+  MPC_HIP_CHECK(hipMemsetAsync(A.dst.count, 0, sizeof(int32_t), ts));
+  int64_t waves = (est + 63) / 64 + 1;
+  if (waves > h->tail_waves) waves = h->tail_waves;
+  if (waves < 1) waves = 1;
   const bool f32 = !h->tail_double, io32 = h->params.precision == MPC_PRECISION_F32;
-  const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
   const int64_t tail_stride = f32 ? h->ws_stride_f32 : h->ws_stride_f64;
-  for (int first = 0; first < n; first += kTailPerLaunch) {
-    const int m = n - first < kTailPerLaunch ? n - first : kTailPerLaunch;
-    MpcTailArgs A;
-    memset(&A, 0, sizeof(A));
-    const int64_t L = h->n_tail_launch;
-    hipStream_t ts = h->tail_stream[si];
-    for (int a = 0; a < m; a++) {
-      const int q = order[first + a];
+  if (f32 && h->occ2)
+    hipLaunchKernelGGL((mpc_tail_slice_kernel<true, float, 2>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)h->tail_ws, tail_stride);
+  else if (f32)
+    hipLaunchKernelGGL((mpc_tail_slice_kernel<true, float, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)h->tail_ws, tail_stride);
+  else if (io32)       /* the fp64 phase of a mixed-precision solve: fp32 arrays at the ABI */
+    hipLaunchKernelGGL((mpc_tail_slice_kernel<true, double, 1, float>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)h->tail_ws, tail_stride);
+  else
+    hipLaunchKernelGGL((mpc_tail_slice_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)h->tail_ws, tail_stride);
+  MPC_HIP_CHECK(hipGetLastError());
+  /* what the pump reads when the slice has completed: the survivors it left, what each absorbed batch handed over, the final flags */
+  MpcHandle::SliceRes *res = h->h_res + kr;
+  MPC_HIP_CHECK(hipMemcpyAsync(&res->dst_count, A.dst.count, sizeof(int32_t), hipMemcpyDeviceToHost, ts));
+  for (int j = 1; j < A.n_src; j++) MPC_HIP_CHECK(hipMemcpyAsync(&res->src_count[j], A.src[j].count, sizeof(int32_t), hipMemcpyDeviceToHost, ts));
+  MPC_HIP_CHECK(hipMemcpyAsync(h->h_final + (size_t)kr * kTailMaxRing, h->d_final, sizeof(long long) * h->tail_ring, hipMemcpyDeviceToHost, ts));
+  MPC_HIP_CHECK(hipEventRecord(h->slice_ev[kr], ts));
+  ++h->n_slice;
+  return MPC_OK;
+}
+
+/* Retires the completed slices in order (`block`: waits for the oldest one in flight first).  Returns how many it retired. */
+static int tail_retire(MpcHandle *h, bool block, int *n_retired) {
+  *n_retired = 0;
+  while (h->n_slice_done < h->n_slice) {
+    const int kr = (int)(h->n_slice_done % kSliceRing);
+    if (block) MPC_HIP_CHECK(hipEventSynchronize(h->slice_ev[kr]));
+    else {
+      const hipError_t e = hipEventQuery(h->slice_ev[kr]);
+      if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+      if (e != hipSuccess) { g_last_error = std::string("hipEventQuery: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
+    }
+    block = false;
+    const MpcHandle::SliceRes &res = h->h_res[kr];
+    h->surv_last = res.dst_count < h->surv_cap ? res.dst_count : h->surv_cap;
+    for (int a = 0; a < h->slice_nabs[kr]; a++) {
+      MpcHandle::FreshQ &F = h->fq[h->slice_abs[kr][a]];
+      const int64_t c = res.src_count[1 + a] < h->tail_cap ? res.src_count[1 + a] : h->tail_cap;
+      if (h->tslot[F.slot].batch_id == F.batch_id) {
+        h->tslot[F.slot].deferred = c;
+        const int64_t Bs = h->tslot[F.slot].B > 0 ? h->tslot[F.slot].B : 1;
+        const int64_t share = c * 65536 / Bs;
+        h->auto_share = h->auto_share < 0 ? share : (3 * h->auto_share + share) / 4;
+        if (h->params.tail_cut < 0 && ++h->auto_since >= 4) {
+          if (h->auto_share > h->auto_hi && h->auto_cut < 96) { ++h->auto_cut; h->auto_since = 0; }
+          else if (h->auto_share < h->auto_lo && h->auto_cut > 8) { --h->auto_cut; h->auto_since = 0; }
+        }
+      }
+      h->fresh_avg = (3 * h->fresh_avg + c + 3) / 4;
+      F.state = 0;
+    }
+    h->slice_nabs[kr] = 0;
+    const long long *fin = h->h_final + (size_t)kr * kTailMaxRing;
+    for (int q = 0; q < h->tail_ring; q++) {
       MpcHandle::TailSlot &S = h->tslot[q];
-      MPC_HIP_CHECK(hipStreamWaitEvent(ts, S.bulk, 0));
-      MpcTailSlot &D = A.slot[a];
-      D.out = S.out; D.traj = S.traj; D.status = S.status; D.iters = S.iters; D.ldo = S.ldo;
-      D.count = h->d_tcount + q; D.inst = h->d_tinst + (int64_t)q * cp; D.park = h->d_tpark + (int64_t)q * kTailRows * cp;
-      D.iter = (const char *)h->d_titer + (size_t)q * h->titer_slot_bytes;
-      S.launch = L;
+      if (S.batch_id != 0 && !S.final_ && fin[q] == (long long)S.batch_id) { S.final_ = true; --h->n_not_final; }
     }
-    A.n_slots = m; A.cap = (int32_t)cp; A.take = h->d_ttake + (L % kTailMaxRing);
-    A.refill_min = 1; A.refill_wait = 0;       /* a finished lane is served at once: the waves of this launch are few and long-lived */
-    MPC_HIP_CHECK(hipMemsetAsync(A.take, 0, sizeof(int32_t), ts));
-    int64_t waves = (int64_t)m * (cp / 64);
-    if (waves > h->tail_waves) waves = h->tail_waves;
-    void *wsp = (char *)h->tail_ws + (size_t)si * (size_t)tail_stride * (size_t)h->tail_waves * real_bytes;
-    if (f32 && h->occ2)
-      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 2>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, tail_stride);
-    else if (f32)
-      hipLaunchKernelGGL((mpc_tail_kernel<true, float, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<float>(), ts, h->params, A, (float *)wsp, tail_stride);
-    else if (io32)       /* the fp64 phase of a mixed-precision solve: fp32 arrays at the ABI */
-      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1, float>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, tail_stride);
-    else
-      hipLaunchKernelGGL((mpc_tail_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)wsp, tail_stride);
-    MPC_HIP_CHECK(hipGetLastError());
-    MPC_HIP_CHECK(hipEventRecord(h->tail_ev[L % kTailMaxRing], ts));
-    h->stream_launch[si] = L;
-    ++h->n_tail_launch;
+    ++h->n_slice_done;
+    ++*n_retired;
   }
   return MPC_OK;
 }
 
-/* self-clocked: a tail stream whose previous launch has finished takes everything that came in meanwhile */
-static int tail_clock(MpcHandle *h) {
-  for (int q = 0; q < h->n_tail_streams; q++) {
-    bool idle = h->stream_launch[q] < 0;
-    if (!idle) {
-      const hipError_t e = hipEventQuery(h->tail_ev[h->stream_launch[q] % kTailMaxRing]);
-      if (e == hipSuccess) idle = true;
-      else if (e != hipErrorNotReady) { g_last_error = std::string("hipEventQuery: ") + hipGetErrorString(e); return MPC_ERR_HIP; }
-      else (void)hipGetLastError();
-    }
-    if (idle) return tail_flush(h, q);
+static bool tail_has_filled(const MpcHandle *h) {
+  for (int q = 0; q < kFreshRing; q++) if (h->fq[q].state == 1) return true;
+  return false;
+}
+
+/* One turn of the pump: retire what has completed, start slices while fewer than two are in flight and there is (or may be)
+ * something for them to do.  `block`: wait for the oldest slice in flight, or -- if none is -- for the launches whose fresh
+ * queues are filled, so that every call makes progress towards "everything final". */
+static int tail_pump(MpcHandle *h, bool block) {
+  if (!h->tail_ready) return MPC_OK;
+  int n = 0;
+  int rc = tail_retire(h, block && h->n_slice_done < h->n_slice, &n);
+  if (rc != MPC_OK) return rc;
+  for (int turn = 0; turn < 2 && h->n_slice - h->n_slice_done < 2; turn++) {
+    const bool in_flight = h->n_slice_done < h->n_slice;
+    const bool filled = tail_has_filled(h);
+    const bool force = block && !in_flight && h->surv_last == 0 && n == 0;
+    bool ready = false;
+    if (filled && !force)
+      for (int q = 0; q < kFreshRing && !ready; q++)
+        if (h->fq[q].state == 1) { const hipError_t e = hipEventQuery(h->fq[q].bulk); if (e == hipSuccess) ready = true; else (void)hipGetLastError(); }
+    /* (survivors: the slice in flight leaves some if the one before it did -- the second slice takes them along as its
+     * source 0 whatever their number, so no time passes between two slices while the host is elsewhere) */
+    if (!(ready || (filled && force) || h->surv_last > 0)) break;
+    rc = tail_launch_slice(h, force);
+    if (rc != MPC_OK) return rc;
   }
   return MPC_OK;
 }
 
-/* the queue slot that holds batch `id`, or nullptr: the batch was not deferred, or it is so old that its slot has been
- * taken again -- which only happens after its tail launch has been waited for */
-static MpcHandle::TailSlot *tail_slot_of(MpcHandle *h, int64_t id) {
-  for (int q = 0; q < h->tail_ring; q++)
-    if (h->tslot[q].batch_id == id) return &h->tslot[q];
-  return nullptr;
+/* everything handed over so far is finished (blocks) */
+static int tail_drain(MpcHandle *h) {
+  if (!h->tail_ready) return MPC_OK;
+  for (int guard = 0; guard < (1 << 24); guard++) {
+    if (h->n_not_final == 0 && h->n_slice_done == h->n_slice && !tail_has_filled(h) && h->surv_last == 0) return MPC_OK;
+    const int rc = tail_pump(h, true);
+    if (rc != MPC_OK) return rc;
+  }
+  g_last_error = "tail_drain: no progress";
+  return MPC_ERR_HIP;
 }
 
 extern "C" int64_t mpc_last_batch_id(const MpcHandle *h) { return h ? h->batch_seq : 0; }
@@ -1316,59 +1520,115 @@ extern "C" int64_t mpc_last_batch_id(const MpcHandle *h) { return h ? h->batch_s
 extern "C" int mpc_tail_flush(MpcHandle *h) {
   if (!h) return MPC_ERR_INVALID;
   MPC_ON_DEVICE(h);
-  return tail_flush(h, -1);
+  return tail_pump(h, false);
+}
+
+/* 1: batch `id` is final, 0: not yet (after one non-blocking turn of the pump); < 0: error */
+static int tail_poll_id(MpcHandle *h, int64_t id, bool pump) {
+  if (id <= 0 || id > h->batch_seq) { g_last_error = "no such batch id"; return MPC_ERR_INVALID; }
+  if (!h->brec) { g_last_error = "no such batch id"; return MPC_ERR_INVALID; }
+  MpcHandle::BatchRec &R = h->brec[id % MpcHandle::kBatchRecs];
+  if (R.id != id) { g_last_error = "batch id too old to resolve (the handle keeps the last 1024)"; return MPC_ERR_INVALID; }
+  if (R.kind == 2) return 1;                           /* an empty batch */
+  if (R.kind == 0) {
+    const hipError_t e = hipEventQuery(R.ev);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();
+    if (e == hipErrorNotReady) return 0;
+    g_last_error = std::string("hipEventQuery: ") + hipGetErrorString(e);
+    return MPC_ERR_HIP;
+  }
+  const MpcHandle::TailSlot &S = h->tslot[R.slot];
+  if (S.batch_id != id || S.final_) return 1;        /* (a slot is only taken again once its batch is final) */
+  if (pump) { const int rc = tail_pump(h, false); if (rc != MPC_OK) return rc; }
+  return (S.batch_id != id || S.final_) ? 1 : 0;
+}
+
+extern "C" int mpc_tail_poll(MpcHandle *h, int64_t batch_id) {
+  if (!h) return MPC_ERR_INVALID;
+  MPC_ON_DEVICE(h);
+  return tail_poll_id(h, batch_id, true);
 }
 
 extern "C" int mpc_tail_wait(MpcHandle *h, int64_t batch_id) {
   if (!h) return MPC_ERR_INVALID;
-  if (!h->tail_ready) return MPC_OK;
   MPC_ON_DEVICE(h);
-  if (batch_id <= 0) {                         /* everything handed over so far */
-    const int rf = tail_flush(h, -1);
-    if (rf != MPC_OK) return rf;
-    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
+  if (batch_id <= 0) {                         /* every batch issued so far: the deferring ones, and the launches of the rest */
+    const int rc = tail_drain(h);
+    if (rc != MPC_OK) return rc;
+    if (h->brec)
+      for (int64_t id = h->batch_seq; id > 0 && id > h->batch_seq - MpcHandle::kBatchRecs; --id) {
+        MpcHandle::BatchRec &R = h->brec[id % MpcHandle::kBatchRecs];
+        if (R.id == id && R.kind == 0 && R.ev) MPC_HIP_CHECK(hipEventSynchronize(R.ev));
+      }
     return MPC_OK;
   }
-  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
-  if (!S) return MPC_OK;
-  if (S->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
-  if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;     /* its event has been recycled: that launch is long done */
-  MPC_HIP_CHECK(hipEventSynchronize(h->tail_ev[S->launch % kTailMaxRing]));
-  return MPC_OK;
+  for (int guard = 0; guard < (1 << 24); guard++) {
+    const int r = tail_poll_id(h, batch_id, false);
+    if (r < 0) return r;
+    if (r == 1) return MPC_OK;
+    MpcHandle::BatchRec &R = h->brec[batch_id % MpcHandle::kBatchRecs];
+    if (R.kind == 0) { MPC_HIP_CHECK(hipEventSynchronize(R.ev)); return MPC_OK; }
+    const int rc = tail_pump(h, true);
+    if (rc != MPC_OK) return rc;
+  }
+  g_last_error = "mpc_tail_wait: no progress";
+  return MPC_ERR_HIP;
 }
 
 extern "C" int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream) {
   if (!h) return MPC_ERR_INVALID;
-  if (!h->tail_ready) return MPC_OK;
   MPC_ON_DEVICE(h);
-  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
-  if (!S) return MPC_OK;
-  if (S->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
-  if (h->n_tail_launch - S->launch > kTailMaxRing) return MPC_OK;
-  MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->tail_ev[S->launch % kTailMaxRing], 0));
+  if (batch_id <= 0 || batch_id > h->batch_seq || !h->brec) { g_last_error = "no such batch id"; return MPC_ERR_INVALID; }
+  MpcHandle::BatchRec &R = h->brec[batch_id % MpcHandle::kBatchRecs];
+  if (R.id != batch_id) { g_last_error = "batch id too old to resolve (the handle keeps the last 1024)"; return MPC_ERR_INVALID; }
+  if (R.kind == 2) return MPC_OK;
+  if (R.kind == 0) {                           /* not deferring: final behind its own launch */
+    MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, R.ev, 0));
+    return MPC_OK;
+  }
+  /* a deferring batch is final behind a slice that has not been issued yet: the host brings it there (the pump is what starts
+   * slices), then orders `stream` behind the tail stream's most recent slice */
+  const int rc = mpc_tail_wait(h, batch_id);
+  if (rc != MPC_OK) return rc;
+  if (h->n_slice > 0) MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->slice_ev[(h->n_slice - 1) % kSliceRing], 0));
   return MPC_OK;
 }
 
-/* counters of the handle's tail machinery: out[0] batches deferred so far, [1] tail launches so far, [2] ring, [3] queue
- * capacity per batch, [4] waves per tail launch (upper bound), [5] 1 if the tail streams have high priority, [6] tail streams */
-extern "C" int mpc_tail_info(const MpcHandle *h, int64_t *out6) {   /* (seven values) */
-  if (!h || !out6) return MPC_ERR_INVALID;
-  out6[0] = h->n_deferred; out6[1] = h->n_tail_launch; out6[2] = h->tail_ring; out6[3] = h->tail_cap; out6[4] = h->tail_waves;
-  out6[5] = h->tail_priority < 0 ? 1 : 0; out6[6] = h->n_tail_streams;
+/* counters of the handle's tail machinery: out[0] batches deferred so far, [1] tail slices so far, [2] ring, [3] capacity of a
+ * batch's fresh queue, [4] waves per slice (upper bound), [5] 1 if the tail stream has high priority, [6] tail streams (1),
+ * [7] batches that ran without deferral because the survivors' list was filling up, [8] passes per slice, [9] survivors now */
+extern "C" int mpc_tail_info(const MpcHandle *h, int64_t *out) {
+  if (!h || !out) return MPC_ERR_INVALID;
+  out[0] = h->n_deferred; out[1] = h->n_slice; out[2] = h->tail_ring; out[3] = h->tail_cap; out[4] = h->tail_waves;
+  out[5] = h->tail_priority < 0 ? 1 : 0; out[6] = 1; out[7] = h->n_throttled; out[8] = h->slice_passes; out[9] = h->surv_last;
+  out[10] = h->params.tail_cut > 0 ? h->params.tail_cut : (h->params.tail_cut < 0 ? h->auto_cut : 0); out[11] = h->auto_share;
   return MPC_OK;
 }
 
 extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
   if (!h || !n) return MPC_ERR_INVALID;
   *n = 0;
-  if (!h->tail_ready) return MPC_OK;
+  if (!h->tail_ready || !h->brec || batch_id <= 0 || batch_id > h->batch_seq) return MPC_OK;
   MPC_ON_DEVICE(h);
-  MpcHandle::TailSlot *S = tail_slot_of(h, batch_id);
-  if (!S) return MPC_OK;
-  MPC_HIP_CHECK(hipEventSynchronize(S->bulk));
-  int32_t c = 0;
-  MPC_HIP_CHECK(hipMemcpy(&c, h->d_tcount + (S - h->tslot), sizeof(c), hipMemcpyDeviceToHost));
-  *n = c < h->tail_cap ? c : h->tail_cap;
+  MpcHandle::BatchRec &R = h->brec[batch_id % MpcHandle::kBatchRecs];
+  if (R.id != batch_id || R.kind == 0) return MPC_OK;
+  MpcHandle::TailSlot &S = h->tslot[R.slot];
+  if (S.batch_id != batch_id) return MPC_OK;            /* long final: its slot holds a later batch */
+  if (S.deferred >= 0) { *n = S.deferred; return MPC_OK; }
+  for (int q = 0; q < kFreshRing; q++)
+    if (h->fq[q].batch_id == batch_id && h->fq[q].state != 0) {
+      MPC_HIP_CHECK(hipEventSynchronize(h->fq[q].bulk));
+      int32_t c = 0;
+      MPC_HIP_CHECK(hipMemcpy(&c, h->fq_dev[q].count, sizeof(c), hipMemcpyDeviceToHost));
+      *n = c < h->tail_cap ? c : h->tail_cap;
+      return MPC_OK;
+    }
+  /* absorbed and retired in the meantime */
+  int nr = 0;
+  const int rc = tail_retire(h, false, &nr);
+  if (rc != MPC_OK) return rc;
+  *n = S.deferred >= 0 ? S.deferred : 0;
   return MPC_OK;
 }
 
@@ -1423,7 +1683,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.compact_cooldown = h->compact_cooldown;
   const unsigned waves2 = (waves + (unsigned)h->finish_div - 1) / (unsigned)h->finish_div;
   /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
-  U.tail_cut = tail.tail_cut; U.t_cap = tail.t_cap; U.t_count = tail.t_count; U.t_inst = tail.t_inst; U.t_park = tail.t_park; U.t_iter = tail.t_iter;
+  U.tail_cut = tail.tail_cut; U.t_slot = tail.t_slot; U.t_batch = tail.t_batch; U.tq = tail.tq;
   hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves2), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
   MPC_HIP_CHECK(hipGetLastError());
@@ -1447,7 +1707,12 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
   h->last_B = B; h->timed = false; h->have_stats = false;
   ++h->batch_seq;
-  if (B == 0) return MPC_OK;   /* empty batch: nothing to read or write, pointers may be NULL */
+  if (B == 0) {                /* empty batch: nothing to read or write, pointers may be NULL; its id resolves as final */
+    if (!h->brec) h->brec = new MpcHandle::BatchRec[MpcHandle::kBatchRecs];
+    MpcHandle::BatchRec &R0 = h->brec[h->batch_seq % MpcHandle::kBatchRecs];
+    R0.id = h->batch_seq; R0.kind = 2;
+    return MPC_OK;
+  }
   if (!state || !coeffs || !yaw_lo || !yaw_hi || !out || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
   MPC_ON_DEVICE(h);   /* workspace, lazy allocations and a NULL stream all belong to the handle's device */
   hipStream_t s = (hipStream_t)stream_;   /* NULL = HIP's default (null) stream, exactly as passed */
@@ -1455,39 +1720,51 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  const bool defer = may_defer && h->params.tail_cut > 0 && B >= h->tail_min_batch && (h->mixed || !(h->lds_lanes > 0 && B <= h->lds_max_batch));
-  const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
-  MpcHandle::TailSlot *ts = nullptr;
-  int slot_index = 0;
+  bool defer = may_defer && h->params.tail_cut != 0 && B >= h->tail_min_batch && (h->mixed || !(h->lds_lanes > 0 && B <= h->lds_max_batch));
+  MpcHandle::BatchRec *rec = nullptr;
+  { const int rc = batch_rec(h, h->batch_seq, &rec); if (rc != MPC_OK) return rc; }
+  rec->id = 0;                                      /* (valid once the launch has been issued) */
+  int slot_index = 0, fq_index = 0;
   if (defer) {
-    const int rc = tail_prepare(h);
+    int rc = tail_prepare(h);
     if (rc != MPC_OK) return rc;
-    slot_index = (int)(h->n_deferred % h->tail_ring);
-    ts = &h->tslot[slot_index];
-    if (ts->batch_id != 0) {
-      /* the queue slot is taken again: whatever it held must have been served (if the tails are slower than ring x
-       * batches, this is where the caller's stream waits for them) */
-      if (ts->launch < 0) { const int rf = tail_flush(h, -1); if (rf != MPC_OK) return rf; }
-      MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->tail_ev[ts->launch % kTailMaxRing], 0));
-    }
-    MPC_HIP_CHECK(hipMemsetAsync(h->d_tcount + slot_index, 0, sizeof(int32_t), (hipStream_t)stream_));
+    rc = tail_pump(h, false);
+    if (rc != MPC_OK) return rc;
+    /* the survivors' list is filling up (stragglers arrive faster than the slices finish them): this batch keeps its own */
+    if (2 * h->surv_last > h->surv_cap) { defer = false; ++h->n_throttled; }
   }
+  if (defer) {
+    slot_index = (int)(h->n_deferred % h->tail_ring);
+    fq_index = (int)(h->n_deferred % kFreshRing);
+    /* the slot is taken again: the batch it held must be final (only if the ring is shorter than the stragglers' latency) */
+    for (int guard = 0; h->tslot[slot_index].batch_id != 0 && !h->tslot[slot_index].final_; guard++) {
+      if (guard > (1 << 22)) { g_last_error = "deferred tails: no progress"; return MPC_ERR_HIP; }
+      const int rc = tail_pump(h, true);
+      if (rc != MPC_OK) return rc;
+    }
+    /* the fresh queue is taken again: the slice that absorbed its previous batch must have read it */
+    MpcHandle::FreshQ &F = h->fq[fq_index];
+    if (F.state == 1) { const int rc = tail_launch_slice(h, true); if (rc != MPC_OK) return rc; }
+    if (F.state == 2) MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->slice_ev[F.slice % kSliceRing], 0));
+    MPC_HIP_CHECK(hipMemsetAsync(h->fq_dev[fq_index].count, 0, sizeof(int32_t), (hipStream_t)stream_));
+  }
+  const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
   auto tail_fields = [&](MpcPhase &T) {
-    T.tail_cut = defer ? h->params.tail_cut : 0; T.t_cap = (int32_t)h->tail_cap;
-    T.t_count = defer ? h->d_tcount + slot_index : nullptr;
-    T.t_inst = defer ? h->d_tinst + (int64_t)slot_index * h->tail_cap : nullptr;
-    T.t_park = defer ? h->d_tpark + (int64_t)slot_index * kTailRows * h->tail_cap : nullptr;
-    T.t_iter = defer ? (void *)((char *)h->d_titer + (size_t)slot_index * h->titer_slot_bytes) : nullptr;
+    T.tail_cut = defer ? (h->params.tail_cut > 0 ? h->params.tail_cut : h->auto_cut) : 0; T.t_slot = slot_index; T.t_batch = h->batch_seq;
+    if (defer) T.tq = h->fq_dev[fq_index];
   };
+  /* behind the launch: the batch's record (what mpc_tail_wait / _poll / _stream_wait resolve its id with) */
   auto tail_done = [&]() -> int {
-    if (!defer) return MPC_OK;
-    ts->batch_id = h->batch_seq; ts->launch = -1;
-    ts->out = out; ts->traj = traj; ts->status = status; ts->iters = iters; ts->ldo = ldo;
-    MPC_HIP_CHECK(hipEventRecord(ts->bulk, s));
+    rec->id = h->batch_seq; rec->kind = defer ? 1 : 0; rec->slot = slot_index;
+    if (!defer) { MPC_HIP_CHECK(hipEventRecord(rec->ev, s)); return MPC_OK; }
+    MpcHandle::FreshQ &F = h->fq[fq_index];
+    F.batch_id = h->batch_seq; F.slot = slot_index; F.state = 1; F.slice = -1;
+    MPC_HIP_CHECK(hipEventRecord(F.bulk, s));
+    MpcHandle::TailSlot &S = h->tslot[slot_index];
+    S.batch_id = h->batch_seq; S.final_ = false; S.deferred = -1; S.B = B;
+    ++h->n_not_final;
     ++h->n_deferred;
-    /* self-clocked: a tail launch goes out whenever a tail stream has finished its previous one, and serves every batch that
-     * came in meanwhile -- so however long the stragglers take, no launch queues behind another */
-    return tail_clock(h);
+    return tail_pump(h, false);
   };
   if (h->mixed) {
     MpcPhase TT;
@@ -1512,6 +1789,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (rc != MPC_OK) return rc;
     MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
     h->timed = true;
+    { const int rt = tail_done(); if (rt != MPC_OK) return rt; }
     if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
     return MPC_OK;
   }
@@ -1702,12 +1980,7 @@ extern "C" int mpc_synchronize(MpcHandle *h) {
   if (!h) return MPC_ERR_INVALID;
   MPC_ON_DEVICE(h);
   MPC_HIP_CHECK(hipStreamSynchronize(h->stream));
-  if (h->tail_ready) {
-    const int rf = tail_flush(h, -1);
-    if (rf != MPC_OK) return rf;
-    for (int q = 0; q < h->n_tail_streams; q++) MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream[q]));
-  }
-  return MPC_OK;
+  return tail_drain(h);
 }
 
 /* rows of a host array <-> the pinned staging block: on a few threads when there is enough to move (a 65 536-instance batch is
@@ -1797,11 +2070,11 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
   if (h->last_B == 0 || !h->have_stats) return MPC_OK;
   MPC_ON_DEVICE(h);
   MPC_HIP_CHECK(hipEventSynchronize(h->ev_stats));
-  unsigned long long acc[8];
+  unsigned long long acc[kStatWords];
   MPC_HIP_CHECK(hipMemcpy(acc, h->d_stats, sizeof(acc), hipMemcpyDeviceToHost));
   st->n_success = (int64_t)acc[MPC_STATUS_SUCCESS]; st->n_maxiter = (int64_t)acc[MPC_STATUS_MAXITER];
   st->n_linesearch = (int64_t)acc[MPC_STATUS_LINESEARCH]; st->n_infeasible = (int64_t)acc[MPC_STATUS_INFEASIBLE];
-  st->n_numeric = (int64_t)acc[4]; st->iter_sum = (int64_t)acc[5]; st->iter_max = (int32_t)acc[6]; st->n_pending = (int32_t)acc[7];
+  st->n_numeric = (int64_t)acc[4]; st->n_acceptable = (int64_t)acc[8]; st->iter_sum = (int64_t)acc[5]; st->iter_max = (int32_t)acc[6]; st->n_pending = (int32_t)acc[7];
   if (h->timed) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;

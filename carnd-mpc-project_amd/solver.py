@@ -184,6 +184,13 @@ class BatchedMPC:
         """Block until batch `batch_id` is final (0: every batch issued so far)."""
         check(library().mpc_tail_wait(self._h, int(batch_id)), "mpc_tail_wait")
 
+    def tail_poll(self, batch_id):
+        """True if batch `batch_id` is final (one non-blocking turn of the pump that starts tail slices)."""
+        r = library().mpc_tail_poll(self._h, int(batch_id))
+        if r < 0:
+            check(r, "mpc_tail_poll")
+        return bool(r)
+
     def tail_stream_wait(self, batch_id, stream):
         check(library().mpc_tail_stream_wait(self._h, int(batch_id), C.c_void_p(stream.cuda_stream)), "mpc_tail_stream_wait")
 
@@ -196,10 +203,12 @@ class BatchedMPC:
         return int(n.value)
 
     def tail_info(self):
-        a = (C.c_int64 * 7)()
+        a = (C.c_int64 * 12)()
         check(library().mpc_tail_info(self._h, a), "mpc_tail_info")
         return {"batches_deferred": int(a[0]), "tail_launches": int(a[1]), "ring": int(a[2]), "capacity_per_batch": int(a[3]),
-                "waves_per_tail_launch": int(a[4]), "tail_stream_high_priority": bool(a[5]), "tail_streams": int(a[6])}
+                "waves_per_tail_launch": int(a[4]), "tail_stream_high_priority": bool(a[5]), "tail_streams": int(a[6]),
+                "batches_not_deferred_survivors_full": int(a[7]), "passes_per_slice": int(a[8]), "survivors": int(a[9]),
+                "tail_cut_in_use": int(a[10]), "deferred_share": (int(a[11]) / 65536.0 if a[11] >= 0 else None)}
 
     def synchronize(self):
         check(library().mpc_synchronize(self._h), "mpc_synchronize")

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 3
+#define MPC_ABI_VERSION 4
 #define MPC_MAX_TABLE 16
 #define MPC_NW 12      /* Config::weights entries read by FG_eval (Config.h:14-61) */
 #define MPC_NCOEF 5    /* road polynomial, zero padded: fit order is 2..4 (RoadGeometry.cpp:26-34) */
@@ -55,13 +55,18 @@ enum {
   MPC_STATUS_LINESEARCH = 2,   /* step length fell below alpha_min (IPOPT: restoration) */
   MPC_STATUS_INFEASIBLE = 3,   /* initial state outside its own bounds (MPC.cpp:229-239 vs :269-281) */
   MPC_STATUS_NUMERIC = 4,      /* NaN/Inf met */
-  MPC_STATUS_PENDING = 5       /* deferred tails only: handed to the tail queue, final after mpc_tail_wait */
+  MPC_STATUS_PENDING = 5,      /* deferred tails only: handed to the tail queue, final after mpc_tail_wait */
+  MPC_STATUS_ACCEPTABLE = 6    /* IPOPT's STOP_AT_ACCEPTABLE_POINT = CppAD's stop_at_acceptable_point, which MPC.cpp:295-303 prints
+                                * ("Ipopt failed with ...") and returns like every other non-success: acceptable_iter iterates in
+                                * a row within the acceptable_* tolerances, or a line search that ran out of step length at such
+                                * a point */
 };
 
 enum { MPC_BRANCH_FROZEN = 0, MPC_BRANCH_LIVE = 1 };
 enum { MPC_F32_START_OFF = 0, MPC_F32_START_ON = 1, MPC_F32_START_AUTO = 2 };   /* MpcParams.f64_f32_start */
 #define MPC_F32_START_AUTO_N 15
 enum { MPC_PRECISION_F64 = 0, MPC_PRECISION_F32 = 1 };
+enum { MPC_TAIL_OFF = 0, MPC_TAIL_AUTO = -1 };   /* MpcParams.tail_cut */
 
 /* Everything the reference reads from `struct Config` statics on this path
  * (src/utils/Config.h:66-177) AFTER Config::load() has applied its unit
@@ -127,12 +132,13 @@ typedef struct MpcParams {
   double bound_relax_factor;       /* default 1e-8 */
   /* Deferred tails: a launch lasts as long as its slowest instance.  With tail_cut > 0 an instance that
    * is still running after tail_cut passes is handed to the handle's tail queue (status MPC_STATUS_PENDING) and the
-   * launch ends; the queue is drained by a separate launch on the handle's own tail stream while later batches run.
-   * mpc_tail_wait / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
-  int32_t tail_cut;                /* default 0 = off */
-  int32_t tail_ring;               /* batches whose tails may be outstanding at once (2..64), default 32: a batch is final
+   * launch ends; the queue is worked off by short tail slices on the handle's own tail stream while later batches run.
+   * mpc_tail_wait / mpc_tail_poll / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
+  int32_t tail_cut;                /* default 0 = off; MPC_TAIL_AUTO (-1): the handle chooses the cut and keeps adjusting it so that
+                                    * about one instance in a hundred is handed over (results do not depend on the cut) */
+  int32_t tail_ring;               /* batches whose tails may be outstanding at once (2..512), default 128: a batch is final
                                     * only when its slowest straggler is, tens of milliseconds behind its launch */
-  int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 8.  A batch with more keeps the rest in its launch */
+  int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 16.  A batch with more keeps the rest in its launch */
   /* Mixed precision across phases.  MPC_PRECISION_F32 handles: f32_finish = 1 (default) runs the interior-point
    * iteration in fp32 until its barrier parameter has reached mixed_switch_mu and finishes every instance in fp64
    * (same state machine, tol instead of tol_f32, termination polish), fp32 at the ABI; 0 = the pure fp32 solver.
@@ -164,6 +170,22 @@ typedef struct MpcParams {
    * results bit for bit.  Measured: +12-20 % on the weight sweeps of configs[4], -6...-15 % where every instance needs
    * about the same number of iterations (the copy, and late refills that prolong a wave for a few lanes).  Default 0. */
   int32_t f32_phase_refill;
+  /* IPOPT's termination tests beyond `tol` (OptimalityErrorConvergenceCheck; all defaults of IPOPT 3.12 that the reference's
+   * option string MPC.cpp:160-179 leaves alone).  Converged = scaled error <= tol AND unscaled dual infeasibility <=
+   * dual_inf_tol, constraint violation <= constr_viol_tol, complementarity <= compl_inf_tol.  Acceptable = the same with
+   * acceptable_tol and the acceptable_* values; acceptable_iter acceptable iterates in a row, or a failed line search at an
+   * acceptable point, end the solve with MPC_STATUS_ACCEPTABLE; a line search that fails at an almost feasible point
+   * (constraint violation <= 1e-2 tol) is final without the restart that stands in for IPOPT's restoration phase (IPOPT does
+   * not try it there).  acceptable_iter = 0 switches the acceptable-level machinery off (IPOPT's meaning of 0).  fp64 solver
+   * only: the fp32 phases stop by tol_f32. */
+  int32_t acceptable_iter;         /* default 15 */
+  double dual_inf_tol;             /* default 1 */
+  double constr_viol_tol;          /* default 1e-4 */
+  double compl_inf_tol;            /* default 1e-4 */
+  double acceptable_tol;           /* default 1e-6 */
+  double acceptable_dual_inf_tol;  /* default 1e10 */
+  double acceptable_constr_viol_tol;   /* default 1e-2 */
+  double acceptable_compl_inf_tol;     /* default 1e-2 */
   double reserved_d;
 } MpcParams;
 
@@ -172,7 +194,7 @@ typedef struct MpcHandle MpcHandle;
 /* Aggregate statistics of the last batch (diagnostics for bench/tests). */
 typedef struct MpcBatchStats {
   int64_t batch;
-  int64_t n_success, n_maxiter, n_linesearch, n_infeasible, n_numeric;
+  int64_t n_success, n_maxiter, n_linesearch, n_infeasible, n_numeric, n_acceptable;
   int64_t iter_sum;          /* sum of interior-point iterations over the batch */
   int32_t iter_max;
   int32_t n_pending;         /* deferred tails: instances of the batch handed to the tail queue (their iterations are not in iter_sum yet) */
@@ -311,24 +333,36 @@ int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcWireTelemetr
  * solves.  With tail_cut = n the launch of mpc_solve_batch_device(_f32) hands every instance that is still running after
  * n passes to the handle's tail queue and ends: when the call's work on `stream` is complete, every other instance has
  * its final results and the handed-over ones carry status MPC_STATUS_PENDING (mpc_tail_pending counts them).  They are
- * finished by separate launches on the handle's own tail stream -- one launch at a time, each serving whatever the batches
- * since the previous one handed over -- which write the same arrays; results are bitwise those of an undisturbed launch.
+ * carried on by TAIL SLICES on the handle's own high-priority stream: short launches (a bounded number of passes each)
+ * that take the survivors of the slice before them and whatever the launches since have handed over, re-packed into dense
+ * waves every time, and write the same arrays; results are bitwise those of an undisturbed launch.  Slices are started by
+ * the calls below and by every solve call ("the pump"): nothing runs on its own between calls, so a serving loop that has
+ * stopped issuing batches finishes with mpc_tail_wait (or polls).
  * The caller keeps a batch's output arrays alive and does not read its pending entries until the batch is final:
  *   mpc_last_batch_id     id of the batch the most recent solve call issued (ids count up from 1 per handle)
- *   mpc_tail_wait         blocks the host until batch `id` is final (id <= 0: every batch issued so far)
- *   mpc_tail_stream_wait  makes `stream` wait for that instead (e.g. the stream a gather of the results runs on)
- *   mpc_tail_flush        starts a tail launch for everything handed over so far without waiting (optional: the solve
- *                         calls do that themselves whenever the previous tail launch has finished)
- * At most tail_ring batches may be outstanding; issuing one more makes the caller's stream wait for the oldest tail.
+ *   mpc_tail_poll         1 if batch `id` is final, 0 if not yet (runs one turn of the pump, never blocks)
+ *   mpc_tail_wait         blocks the host until batch `id` is final (id <= 0: every batch issued so far); for a batch that
+ *                         did not defer (small batches, tail_cut = 0, the run()/telemetry/rollout/host entry points) that is
+ *                         the completion of its own launch
+ *   mpc_tail_stream_wait  orders `stream` behind the batch being final.  A batch that did not defer: a stream-side wait for its
+ *                         launch, the host does not block.  A deferring batch is final behind slices that do not exist yet,
+ *                         so the host pumps until it is (blocks), then `stream` is ordered behind the tail stream
+ *   mpc_tail_flush        one turn of the pump (optional)
+ * The handle resolves the ids of its last 1 024 batches; older ones return MPC_ERR_INVALID.  At most tail_ring batches may
+ * be outstanding; issuing one more blocks the host until the oldest is final.  The survivors' list is bounded: while it is
+ * more than half full, new batches run without deferral (counted in mpc_tail_info).
  * The run(), telemetry, rollout and host entry points never defer. */
 int64_t mpc_last_batch_id(const MpcHandle *h);
+int mpc_tail_poll(MpcHandle *h, int64_t batch_id);
 int mpc_tail_wait(MpcHandle *h, int64_t batch_id);
 int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream);
 int mpc_tail_flush(MpcHandle *h);
 int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n);   /* waits for the batch's own launch, then: how many it handed over */
-/* out7: batches deferred so far, tail launches so far, ring, queue capacity per batch, waves per tail launch, 1 if the
- * tail streams have high priority, number of tail streams (launches that may run side by side) */
-int mpc_tail_info(const MpcHandle *h, int64_t *out7);
+/* out12: batches deferred so far, tail slices so far, ring, capacity of a batch's fresh queue, waves per slice (upper bound), 1 if the
+ * tail stream has high priority, number of tail streams (1), batches that ran without deferral because the survivors' list was
+ * filling up, passes per slice, survivors after the most recent retired slice, the cut in use (MPC_TAIL_AUTO: the current choice),
+ * running mean of the deferred share of a batch in 1/65536 (-1: none retired yet) */
+int mpc_tail_info(const MpcHandle *h, int64_t *out12);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);

@@ -698,9 +698,17 @@ void orc_default_options(OrcSolveOptions *o) {
   o->lam_init_ls = 1; o->obj_scaling = 1; o->verbose = 0;
   o->polish = 1; o->out_step_tol = 3e-7;
   o->bound_relax_factor = 1e-8; o->honor_original_bounds = 1;
+  o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4;
+  o->acceptable_tol = 1e-6; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
+  o->acceptable_compl_inf_tol = 1e-2; o->acceptable_iter = 15;
 }
 
 typedef struct Filter { double th[256], ph[256]; int n; } Filter;
+
+/* BacktrackingLineSearch::StoreAcceptablePoint / RestoreAcceptablePoint: the most recent iterate that met the
+ * acceptable-level tests.  It outlives an attempt: the caller's stand-in for the restoration phase (a restart) falls back
+ * to it when it fails, as IPOPT does when its restoration phase fails. */
+typedef struct AccPoint { int have; int iter; double *x, *lam, *zl, *zu; OrcSolveInfo info; } AccPoint;
 
 static int filter_rejects(const Filter *F, double th, double ph) {
   for (int i = 0; i < F->n; i++) if (th >= F->th[i] && ph >= F->ph[i]) return 1;
@@ -717,7 +725,7 @@ static double barrier_phi(const Nlp *P, const double *x, double f_scaled, double
 }
 
 static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, double *x,
-                     double *lam_out, OrcSolveInfo *info) {
+                     double *lam_out, OrcSolveInfo *info, AccPoint *acc) {
   const int n = P->I.n, m = P->I.m, nk = n + m;
   const double kappa_eps = 10, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, s_max = 100;
   const double gamma_theta = 1e-5, gamma_phi = 1e-8, delta_sw = 1, s_theta = 1.1, s_phi = 2.3, eta_phi = 1e-8;
@@ -801,7 +809,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   double theta0 = 0; for (int j = 0; j < m; j++) theta0 += fabs(c[j]);
   const double theta_max = 1e4 * fmax(1, theta0), theta_min = 1e-4 * fmax(1, theta0);
   flt->n = 0;
-  int iter, n_polish = 0;
+  int iter, n_polish = 0, acc_count = 0;
   double out_step = DBL_MAX;   /* |alpha d(delta_0, a_0)|_inf of the last accepted step */
   for (iter = 0; iter <= opt->max_iter; iter++) {
     double f = eval_f(P->cfg, &P->tape, x);
@@ -829,20 +837,31 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     info->dual_inf = dinf / df; info->compl_inf = COMPL(0.0) / df; info->iterations = iter;
     if (opt->verbose) fprintf(stderr, "it %3d f=%.10g theta=%.3e dinf=%.3e compl=%.3e mu=%.2e E0=%.3e\n", iter, f, cinf, dinf, COMPL(0.0), mu, E0);
     if (!(E0 == E0)) { status = ORC_NUMERIC_ERROR; break; }
-    if (n_polish > 0 && !(E0 <= opt->tol)) {
+    /* OptimalityErrorConvergenceCheck (IPOPT 3.12): CONVERGED needs the scaled error within tol AND the unscaled dual
+     * infeasibility, constraint violation and complementarity within their own tolerances; ACCEPTABLE is the same test
+     * with the acceptable_* values (see mpc_oracle.h).  (No constraint scaling here: IPOPT's gradient-based scaling would
+     * scale a constraint row only if its gradient at the start point exceeded 100, i.e. a road slope |f'(0)| > 100.) */
+    const double dinf_u = dinf / df, compl_u = COMPL(0.0) / df;
+    const int converged = E0 <= opt->tol && dinf_u <= opt->dual_inf_tol && cinf <= opt->constr_viol_tol && compl_u <= opt->compl_inf_tol;
+    const int acceptable = opt->acceptable_iter > 0 && E0 <= opt->acceptable_tol && dinf_u <= opt->acceptable_dual_inf_tol &&
+                           cinf <= opt->acceptable_constr_viol_tol && compl_u <= opt->acceptable_compl_inf_tol;
+    if (n_polish > 0 && !converged) {
       /* a polish step must not cost what has been reached: one that leaves tol is dropped, the converged iterate returned */
       memcpy(x, x_keep, szn); memcpy(lam, lam_keep, szm); memcpy(zl, zl_keep, szn); memcpy(zu, zu_keep, szn);
       *info = info_keep; status = ORC_SUCCESS; break;
     }
-    if (E0 <= opt->tol) {
-      /* IPOPT stops at the first iterate with E_0 <= tol.  Termination polish (OrcSolveOptions.polish, see
+    if (converged) {
+      /* IPOPT stops at the first converged iterate.  Termination polish (OrcSolveOptions.polish, see
        * mpc_oracle.h): Newton steps at the final barrier parameter until the outputs have stopped moving. */
       if (!opt->polish || n_polish >= 6 || iter == opt->max_iter || (mu <= mu_min_abs && out_step <= opt->out_step_tol)) {
         status = ORC_SUCCESS; break;
       }
       n_polish++;
       if (mu > mu_min_abs) { mu = mu_min_abs; tau = fmax(tau_min, 1 - mu); flt->n = 0; }
-    }
+    } else if (acceptable) {
+      /* acceptable_iter acceptable iterates in a row: CONVERGED_TO_ACCEPTABLE_POINT (tested before max_iter, as IPOPT does) */
+      if (++acc_count >= opt->acceptable_iter) { status = ORC_STOP_AT_ACCEPTABLE; break; }
+    } else acc_count = 0;
     if (iter == opt->max_iter) break;
     /* barrier update (W&B eq. 7), repeated while the barrier problem is already solved */
     for (;;) {
@@ -904,6 +923,11 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
       if (hl[i] && dzl[i] < 0) az = fmin(az, -tau * zl[i] / dzl[i]);
       if (hu[i] && dzu[i] < 0) az = fmin(az, -tau * zu[i] / dzu[i]);
     }
+    /* BacktrackingLineSearch::FindAcceptableTrialPoint begins by storing the current iterate if it is acceptable */
+    if (acceptable && acc && !converged) {
+      acc->have = 1; acc->iter = iter; acc->info = *info;
+      memcpy(acc->x, x, szn); memcpy(acc->lam, lam, szm); memcpy(acc->zl, zl, szn); memcpy(acc->zu, zu, szn);
+    }
     /* filter line search (W&B section 2.3, algorithm A) */
     double theta_k = 0; for (int j = 0; j < m; j++) theta_k += fabs(c[j]);
     double phi_k = barrier_phi(P, x, df * f, mu);
@@ -944,7 +968,14 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     }
     if (!accepted) {
       /* a polish step that finds no acceptable length: the iterate had already met tol, it is the answer */
-      status = (n_polish > 0 && E0 <= opt->tol) ? ORC_SUCCESS : ORC_RESTORATION_FAILURE;
+      if (n_polish > 0 && converged) { status = ORC_SUCCESS; break; }
+      /* IPOPT would now call its restoration phase -- unless the point is acceptable ("restoration phase called at
+       * acceptable point": STOP_AT_ACCEPTABLE_POINT) or almost feasible (constraint violation <= 1e-2 tol: the stored
+       * acceptable point if there is one, otherwise "restoration phase called, but point is almost feasible": a failure
+       * without the restoration phase being tried -- info->no_restart tells the caller's stand-in not to restart either). */
+      if (acceptable) { status = ORC_STOP_AT_ACCEPTABLE; break; }
+      status = ORC_RESTORATION_FAILURE;
+      if (opt->acceptable_iter > 0 && cinf <= 1e-2 * opt->tol) info->no_restart = 1;
       break;
     }
     if (!ftype && flt->n < 256) { flt->th[flt->n] = (1 - gamma_theta) * theta_k; flt->ph[flt->n] = phi_k - gamma_phi * theta_k; flt->n++; }
@@ -969,6 +1000,15 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   }
 #undef COMPL
 #undef EVAL_C
+  /* RestoreAcceptablePoint: a restoration failure that no restart will follow (almost feasible point, or this already is
+   * the restart: `acc` then also holds what the first attempt stored) ends at the stored acceptable point */
+  if (status == ORC_RESTORATION_FAILURE && acc && acc->have && (info->no_restart || !opt->lam_init_ls)) {
+    const int it_now = info->iterations, nreg = info->n_regularised, nbt = info->n_backtracks;
+    memcpy(x, acc->x, szn); memcpy(lam, acc->lam, szm); memcpy(zl, acc->zl, szn); memcpy(zu, acc->zu, szn);
+    *info = acc->info; info->iterations = it_now; info->n_regularised = nreg; info->n_backtracks = nbt;
+    info->acceptable_restored_older = 1;
+    status = ORC_STOP_AT_ACCEPTABLE;
+  }
   info->status = status;
   P->xl = xl_user; P->xu = xu_user;
   if (opt->honor_original_bounds)   /* OrigIpoptNLP::FinalizeSolution: the returned x lies inside the bounds the user gave */
@@ -1030,24 +1070,28 @@ int orc_mpc_solve(const OrcConfig *cfg, const OrcSolveOptions *opt_in, const dou
     for (int rep = 0; rep < 50; rep++) {
       memcpy(x0, rep == 0 ? xi : x, sizeof(double) * I.n);
       tape_decide(cfg, x0, prev);
-      status = ipm_solve(&P, &opt, x0, x, NULL, &info);
+      status = ipm_solve(&P, &opt, x0, x, NULL, &info, NULL);
       Tape *now = (Tape *)malloc(sizeof(Tape)); tape_decide(cfg, x, now);
       int same = !memcmp(now, prev, sizeof(Tape)); free(now);
       if (same || status != ORC_SUCCESS) break;
     }
     free(x0); free(prev);
   } else {
-    status = ipm_solve(&P, &opt, xi, x, NULL, &info);
-    if (status == ORC_RESTORATION_FAILURE && opt.lam_init_ls) {
+    AccPoint acc; acc.have = 0; acc.iter = 0;
+    double *accbuf = (double *)malloc(sizeof(double) * (3 * I.n + I.m));
+    acc.x = accbuf; acc.zl = accbuf + I.n; acc.zu = accbuf + 2 * I.n; acc.lam = accbuf + 3 * I.n;
+    status = ipm_solve(&P, &opt, xi, x, NULL, &info, &acc);
+    if (status == ORC_RESTORATION_FAILURE && opt.lam_init_ls && !info.no_restart) {
       /* IPOPT would switch to its feasibility-restoration phase here, which this oracle does not
        * restate.  Stand-in: restart from the same start point with zero equality multipliers
        * (what IPOPT itself falls back to when the least-squares estimate is rejected). */
       OrcSolveOptions o2 = opt; o2.lam_init_ls = 0;
       OrcSolveInfo i2;
-      int s2 = ipm_solve(&P, &o2, xi, x, NULL, &i2);
+      int s2 = ipm_solve(&P, &o2, xi, x, NULL, &i2, &acc);
       i2.iterations += info.iterations; i2.n_regularised += info.n_regularised; i2.n_backtracks += info.n_backtracks;
       info = i2; status = s2;
     }
+    free(accbuf);
   }
   if (traj_x && traj_y) for (int i = 0; i < I.N; i++) { traj_x[i] = x[I.x + i]; traj_y[i] = x[I.y + i]; }  /* :306-311 */
   out9[0] = x[I.x + 1]; out9[1] = x[I.y + 1]; out9[2] = x[I.psi + 1]; out9[3] = x[I.v + 1];               /* :322-324 */

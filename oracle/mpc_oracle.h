@@ -74,7 +74,8 @@ enum {
   ORC_MAXITER_EXCEEDED = 1,
   ORC_RESTORATION_FAILURE = 2,  /* line search hit alpha_min (IPOPT would enter restoration) */
   ORC_INFEASIBLE_START = 3,     /* initial state violates its own bounds (MPC.cpp:229-239 vs :269-281) */
-  ORC_NUMERIC_ERROR = 4
+  ORC_NUMERIC_ERROR = 4,
+  ORC_STOP_AT_ACCEPTABLE = 6    /* CppAD's stop_at_acceptable_point = IPOPT's STOP_AT_ACCEPTABLE_POINT (5 is the device's PENDING) */
 };
 
 typedef struct OrcSolveOptions {
@@ -97,6 +98,22 @@ typedef struct OrcSolveOptions {
    * caller's bounds (honor_original_bounds = yes, the IPOPT 3.12 default). */
   double bound_relax_factor;
   int honor_original_bounds;
+  /* IPOPT's termination tests beyond `tol`, all defaults of 3.12 that MPC.cpp:160-179 leaves alone
+   * (OptimalityErrorConvergenceCheck): an iterate is CONVERGED when the scaled error E_0 <= tol AND the unscaled dual
+   * infeasibility <= dual_inf_tol (1), constraint violation <= constr_viol_tol (1e-4), complementarity <= compl_inf_tol
+   * (1e-4).  It is ACCEPTABLE when E_0 <= acceptable_tol (1e-6) and the unscaled quantities are within
+   * acceptable_dual_inf_tol (1e10) / acceptable_constr_viol_tol (1e-2) / acceptable_compl_inf_tol (1e-2);
+   * acceptable_iter (15) acceptable iterates in a row end the solve with STOP_AT_ACCEPTABLE_POINT, which
+   * CppAD::ipopt::solve reports as stop_at_acceptable_point and MPC.cpp:295-303 prints and returns like any other
+   * non-success.  The line search keeps the most recent acceptable iterate (BacktrackingLineSearch::
+   * StoreAcceptablePoint): when it runs out of step length AT an acceptable point the solve ends there with the same
+   * status ("restoration phase called at acceptable point"), at an almost feasible point (constraint violation <=
+   * 1e-2 tol) IPOPT does not start its restoration phase at all -- the stored point is returned if there is one,
+   * otherwise the solve fails -- and a failed restoration falls back to the stored point.  acceptable_iter = 0
+   * switches all of it off (IPOPT's own meaning of 0). */
+  double dual_inf_tol, constr_viol_tol, compl_inf_tol;
+  double acceptable_tol, acceptable_dual_inf_tol, acceptable_constr_viol_tol, acceptable_compl_inf_tol;
+  int acceptable_iter;
 } OrcSolveOptions;
 
 typedef struct OrcSolveInfo {
@@ -110,6 +127,8 @@ typedef struct OrcSolveInfo {
   double compl_inf;     /* unscaled max complementarity */
   int n_regularised;    /* iterations that needed delta_w > 0 */
   int n_backtracks;
+  int acceptable_restored_older;   /* 1: STOP_AT_ACCEPTABLE returned a stored iterate that was not the current one */
+  int no_restart;       /* 1: the line search failed at an almost feasible point: IPOPT does not try its restoration phase there */
 } OrcSolveInfo;
 
 void orc_default_options(OrcSolveOptions *opt);

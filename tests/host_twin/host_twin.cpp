@@ -125,7 +125,7 @@ static int solve_parked_t(const MpcParams *p, int64_t B, int64_t ld, int pass_cu
         const int r = cur->step();
         ++passes;
         if (r != SV::MPC_RUNNING) {
-          if (r == MPC_STATUS_LINESEARCH && attempt == 0) { attempt = 1; it_total += cur->iters; cur->start_point(); cur->begin(false); continue; }
+          if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !cur->no_restart) { attempt = 1; it_total += cur->iters; cur->start_point(); cur->begin(false); continue; }
           s = r; cur->iters += it_total; fin = cur;
           break;
         }
@@ -232,7 +232,7 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
           attempt = 0; it_total += D.iters; D.start_point(); D.begin(true);
           continue;
         }
-        if (r == MPC_STATUS_LINESEARCH && attempt == 0) {
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !(in_double ? D.no_restart : A.no_restart)) {
           attempt = 1;
           if (in_double) { it_total += D.iters; D.start_point(); D.begin(false); }
           else { it_total += A.iters; A.start_point(); A.begin(false); }
@@ -306,7 +306,7 @@ static int traffic_t(const MpcParams *p, int64_t B, int64_t ld, const R *state, 
         const int r = S.step();
         ++passes;
         if (r == SV::MPC_RUNNING) continue;
-        if (r == MPC_STATUS_LINESEARCH && attempt == 0) { attempt = 1; it_total += S.iters; S.start_point(); S.begin(false); continue; }
+        if (r == MPC_STATUS_LINESEARCH && attempt == 0 && !S.no_restart) { attempt = 1; it_total += S.iters; S.start_point(); S.begin(false); continue; }
         break;
       }
     }

@@ -37,13 +37,18 @@ class OrcSolveOptions(C.Structure):
     _fields_ = [("branch_mode", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
                 ("lam_init_ls", C.c_int), ("obj_scaling", C.c_int), ("verbose", C.c_int),
                 ("polish", C.c_int), ("out_step_tol", C.c_double),
-                ("bound_relax_factor", C.c_double), ("honor_original_bounds", C.c_int)]
+                ("bound_relax_factor", C.c_double), ("honor_original_bounds", C.c_int),
+                ("dual_inf_tol", C.c_double), ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double),
+                ("acceptable_tol", C.c_double), ("acceptable_dual_inf_tol", C.c_double),
+                ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
+                ("acceptable_iter", C.c_int)]
 
 
 class OrcSolveInfo(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("kkt_error", C.c_double), ("mu", C.c_double),
                 ("obj", C.c_double), ("constr_viol", C.c_double), ("dual_inf", C.c_double),
-                ("compl_inf", C.c_double), ("n_regularised", C.c_int), ("n_backtracks", C.c_int)]
+                ("compl_inf", C.c_double), ("n_regularised", C.c_int), ("n_backtracks", C.c_int),
+                ("acceptable_restored_older", C.c_int), ("no_restart", C.c_int)]
 
 
 class OrcRunPre(C.Structure):

@@ -1,0 +1,39 @@
+#!/bin/bash
+# The GPU sessions of round 4 (one parameterised script; run from the repo root through gpurun):
+#   bash tools/r04_session.sh a     survey population: tail waves x tail cut; N = 25 PMC passes
+set -o pipefail
+S=${1:-a}
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+P=$OUT/r04${S}_progress.log
+echo "== start $S" | tee $P
+run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r04${S}_$tag.json 2> $OUT/r04${S}_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+import json
+try:
+    r = json.load(open("$OUT/r04${S}_$tag.json"))
+    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  kernel_ms %.3f tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["roofline"]["kernel_ms_avg"], r["config"]["deferred_tails"] if isinstance(r["config"]["deferred_tails"], str) else {k: r["config"]["deferred_tails"][k] for k in ("tail_launches", "instances_over_the_cut_in_the_last_batch", "waves_per_tail_launch")}))
+except Exception as e:
+    print("   $tag: no result", e)
+PY
+}
+pmc() { tag=$1; ctrs=$2; shift 2; ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/r04${S}_pmc_$tag -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-host-leg --no-legs "$@" > /dev/null 2> $OUT/r04${S}_pmc_$tag.err ); echo "pmc $tag exit=$?" | tee -a $P; }
+case $S in
+a)
+  export GPU_MAX_HW_QUEUES=8
+  run head_c0 --steps 200
+  for w in 8 16 32 64 256; do MPC_TAIL_WAVES=$w run survey_c20_w$w --steps 600 --population survey --tail-cut 20 --tail-ring 64; done
+  for c in 24 28 32 40; do MPC_TAIL_WAVES=32 run survey_c${c}_w32 --steps 600 --population survey --tail-cut $c --tail-ring 64; done
+  for c in 24 32; do MPC_TAIL_WAVES=16 run survey_c${c}_w16 --steps 600 --population survey --tail-cut $c --tail-ring 64; done
+  MPC_TAIL_WAVES=32 MPC_TAIL_STREAMS=1 run survey_c24_w32_st1 --steps 600 --population survey --tail-cut 24 --tail-ring 64
+  MPC_TAIL_WAVES=32 MPC_TAIL_STREAMS=3 run survey_c24_w32_st3 --steps 600 --population survey --tail-cut 24 --tail-ring 64
+  MPC_TAIL_WAVES=32 MPC_TAIL_PRIORITY=normal run survey_c24_w32_np --steps 600 --population survey --tail-cut 24 --tail-ring 64
+  # N = 25 (configs[3] share): r04 PMC passes of the single-phase fp64 solve
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4 --tail-cut 24 --tail-ring 64"
+  run n25 --steps 60 $N25
+  MPC_TAIL_WAVES=32 run n25_w32 --steps 60 $N25
+  MPC_LANE_COMPACT=1 run n25_lc1 --steps 60 $N25
+  pmc n25_fetch FETCH_SIZE --steps 6 --warmup 4 $N25
+  pmc n25_write WRITE_SIZE --steps 6 --warmup 4 $N25
+  pmc n25_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --steps 6 --warmup 4 $N25
+  ;;
+esac
+echo done | tee -a $P
