@@ -74,7 +74,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
            "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device",
-           "mpc_last_batch_id", "mpc_tail_poll", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
+           "mpc_run_batch_host", "mpc_last_batch_id", "mpc_tail_poll", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
 
 _lib = None
 
@@ -127,6 +127,7 @@ def library():
     L.mpc_debug_math_ext.argtypes = [C.c_int, C.c_int64] + [C.c_void_p] * 6
     L.mpc_debug_tile_pool.argtypes = [C.c_void_p, C.c_void_p]
     L.mpc_run_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
+    L.mpc_run_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 8
     L.mpc_telemetry_batch_device.argtypes = ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 5 +
                                              [C.c_void_p])
     L.mpc_rollout_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]

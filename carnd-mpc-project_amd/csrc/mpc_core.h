@@ -220,7 +220,8 @@ struct TiledWorkspace {
    * one M0 value (immediates 0, 1024, 2048, 3072).  Written as assembly because the compiler expands the
    * builtin's offset argument back into per-copy address arithmetic (5 issue slots per copy instead of <2).
    * The compiler does not see these as memory instructions; that only makes its own vmcnt waits more
-   * conservative (vmcnt completes in order), and the sweeps order everything staged with explicit waits. */
+   * conservative (vmcnt completes in order), and the sweeps order everything staged with explicit waits.
+   * M0 is written by every statement and is in its clobber list: the compiler keeps nothing of its own there across one. */
   template <int NG>
   MPC_HD void dma(int buf, int k, int I, int f0, int dst_group) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -233,16 +234,16 @@ struct TiledWorkspace {
       if (q0 + 4 <= n)
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
-                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else if (q0 + 3 == n)
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:2048"
-                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else if (q0 + 2 == n)
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                     :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+                     :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(src), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
     }
 #endif
   }

@@ -56,10 +56,11 @@ constexpr int kBlock = 64; /* one wavefront per workgroup: lanes never synchroni
 constexpr int64_t kLdsPerCu = 160 * 1024;
 constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
 constexpr int kCounterInts = 16;    /* two counters per phase */
+constexpr int kCounterRing = 32;    /* counter blocks: solve call n uses block n % 32 and zeroes block (n + 16) % 32 for its next user */
 constexpr int kParkRows = 37;       /* Solver::PARK_N */
 constexpr int kFinPromote = -2, kFinScratch = -3;   /* a lane that waits to hand its instance to the fp64 phase (promoted / to be solved from scratch) */
 constexpr int kTailMaxRing = 512;   /* deferred tails: batches whose stragglers may be outstanding at once */
-constexpr int kFreshRing = 8;       /* fresh queues: one per batch between its launch and the tail slice that absorbs its stragglers */
+constexpr int kFreshRing = 24;      /* fresh queues: one per batch between its launch and the completion of the tail slice that absorbs its stragglers */
 constexpr int kSliceMaxSrc = 1 + kFreshRing;   /* what one tail slice reads: the survivors of the slice before it + fresh queues */
 constexpr int kSliceRing = 4;       /* slices whose events and result blocks are kept (at most two are in flight) */
 constexpr int kTailInRows = 6 + MPC_NCOEF + 2 + MPC_NW;   /* the inputs of a deferred instance travel with it: 25 rows */
@@ -157,12 +158,44 @@ struct MpcPhase {
    * once -- and reported as MPC_STATUS_PENDING; mpc_tail_kernel finishes it from another stream.  A full queue (t_cap) makes
    * the instance finish here after all. */
   int32_t tail_cut, t_slot;        /* t_slot: the batch's slot in the handle's ring (its live-instance counter, its final flag) */
+  /* ... and a wave does not wait for its last few lanes: once the launch has no work left to hand out and at most tail_few of
+   * a wave's lanes are still running (after tail_few_from passes), they are handed over too and the wave leaves.  A launch
+   * of one instance per lane lasts as long as its waves do, a wave as long as the slowest of its 64 instances: the mean of
+   * that maximum is 19 passes on the survey population with a cut at 20, 17.3 when the last two lanes are not waited for
+   * (2.6 % of the instances handed over instead of 1.1 %). */
+  int32_t tail_few, tail_few_from;
   int64_t t_batch;                 /* the batch's id */
   MpcTailQ tq;                     /* the batch's fresh queue */
+  int32_t *zero_next;              /* first launch of a solve call: kCounterInts counters to reset for a later call (no memset launches on
+                                    * the stream: on a full device each of those little launches waits for a free SIMD) */
   unsigned long long *pool_bits;   /* [8][pool_words]: bit set = tile free; nullptr = no pool */
   void *pool_base;                 /* [8][pool_tiles] tiles */
   int32_t pool_tiles, pool_words;  /* per XCD */
 };
+
+/* Copies between queue entries and a lane's workspace column.  Loads first, then stores, a stage (or 16 rows) at a time: written as
+ * `dst[..] = src[..]` in one loop the compiler must assume that a store aliases the next load and waits for every load before the
+ * next one goes out -- 200 round trips of ~2 us per entry, which priced a wave's life at +10 % per deferred instance. */
+template <class R, class WS>
+__device__ __forceinline__ void tile_from_column(R *__restrict__ dst, const WS &ws, int I, int M) {      /* dst: lane's place in a [M][IT_SZ][64] tile */
+  using FL = mpc::Fields<R>;
+  for (int k = 0; k < M; ++k) {
+    R rec[FL::IT_SZ];
+#pragma unroll
+    for (int f = 0; f < FL::IT_SZ; f++) rec[f] = ws.it(k, I, f);
+#pragma unroll
+    for (int f = 0; f < FL::IT_SZ; f++) dst[(k * FL::IT_SZ + f) * 64] = rec[f];
+  }
+}
+__device__ __forceinline__ void rows_copy(double *__restrict__ dk, int64_t dl, const double *__restrict__ pk, int64_t lp, int q0, int q1) {
+  for (int q = q0; q < q1; q += 16) {
+    double t[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) t[e] = q + e < q1 ? pk[(q + e) * lp] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) if (q + e < q1) dk[(q + e) * dl] = t[e];
+  }
+}
 
 /* OCC = waves per SIMD the register allocation is held to: the fp64 solver needs ~380 registers (1); the fp32 solver
  * fits 256 with a few spilled values (2), or runs unconstrained (1) */
@@ -225,6 +258,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
 #endif
   ws.lane = threadIdx.x;
   ws.lbuf = (typename WS::lreal *)smem;
+  if (T.zero_next && blockIdx.x == 0 && threadIdx.x < kCounterInts) T.zero_next[threadIdx.x] = 0;
   SV S(P, ws);
   if (T.promote_out) { S.promote_mu = (R)P.mixed_switch_mu; if (T.promote_cap > 0) S.promote_cap = T.promote_cap; }
   int64_t i = 0;
@@ -442,6 +476,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
 #endif
     if (!MPC_WAVE_ANY(have || more || fin)) break;
     ++passes_wave;
+    const bool few = T.tail_few > 0 && !MPC_WAVE_ANY(more) && MPC_WAVE_COUNT(have) <= T.tail_few;
     if (have) {
       const int r = S.step();
       ++passes;
@@ -482,7 +517,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           S.start_point();
           S.begin(false);
         } else { fin = true; fin_status = r; have = false; }
-      } else if (T.tail_cut > 0 && passes >= T.tail_cut && S.phase == SV::PH_DIR && !queue_full) {
+      } else if (T.tail_cut > 0 && (passes >= T.tail_cut || (few && passes >= T.tail_few_from)) && S.phase == SV::PH_DIR && !queue_full) {
         const int pos = atomicAdd(T.tq.count, 1);
         if (pos >= T.tq.cap) queue_full = true;     /* it finishes here, and so does whatever else this lane takes */
         else {
@@ -490,10 +525,18 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           const int64_t lp = T.tq.cap;
           S.park([pk, lp](int q) -> double & { return pk[q * lp]; }, attempt, it_total);
           pk += kParkRows * lp;
-          for (int q = 0; q < 6; q++) pk[q * lp] = (double)state[q * ld + i];
-          for (int q = 0; q < MPC_NCOEF; q++) pk[(6 + q) * lp] = (double)coeffs[q * ld + i];
-          pk[11 * lp] = (double)yaw_lo[i]; pk[12 * lp] = (double)yaw_hi[i];
-          for (int q = 0; q < MPC_NW; q++) pk[(13 + q) * lp] = weights ? (double)weights[q * ld + i] : P.weights[q];
+          {
+            double in[kTailInRows];
+#pragma unroll
+            for (int q = 0; q < 6; q++) in[q] = (double)state[q * ld + i];
+#pragma unroll
+            for (int q = 0; q < MPC_NCOEF; q++) in[6 + q] = (double)coeffs[q * ld + i];
+            in[11] = (double)yaw_lo[i]; in[12] = (double)yaw_hi[i];
+#pragma unroll
+            for (int q = 0; q < MPC_NW; q++) in[13 + q] = weights ? (double)weights[q * ld + i] : P.weights[q];
+#pragma unroll
+            for (int q = 0; q < kTailInRows; q++) pk[q * lp] = in[q];
+          }
           pk += kTailInRows * lp;
           pk[0] = (double)i; pk[lp] = (double)T.t_slot; pk[2 * lp] = (double)T.t_batch;
           pk[3 * lp] = __longlong_as_double((long long)out); pk[4 * lp] = __longlong_as_double((long long)traj);
@@ -501,9 +544,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           pk[7 * lp] = (double)ldo;
           ws.stage_drain();                          /* the trial sweep's stores of this wave have landed */
           const int I = S.cur ? FL::IT1 : FL::IT0, M = P.N - 1;
-          R *dst = (R *)T.tq.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63);
-          for (int k = 0; k < M; ++k)
-            for (int f = 0; f < FL::IT_SZ; f++) dst[(k * FL::IT_SZ + f) * 64] = ws.it(k, I, f);
+          tile_from_column<R>((R *)T.tq.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63), ws, I, M);
           status[i] = MPC_STATUS_PENDING;
           if (iters) iters[i] = S.iters + it_total;
           have = false;                              /* the lane takes its next instance at the next hand-over */
@@ -543,13 +584,17 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
  * be zero before both have happened: partial sums without the addition are negative, with it positive). */
 struct MpcSliceArgs {
   int32_t n_src, budget;           /* sources in use; wave passes after which the slice parks what is still running */
+  int32_t ring, pad_;              /* slots of the handle's ring */
   MpcTailQ src[kSliceMaxSrc];      /* [0]: survivors of the previous slice; [1..]: fresh queues absorbed by this slice */
   int32_t fresh_slot[kSliceMaxSrc];
   int64_t fresh_batch[kSliceMaxSrc];
   MpcTailQ dst;                    /* survivors of this slice */
   int32_t *take;                   /* work counter over the concatenated sources */
+  int32_t *done;                   /* waves of this slice that have left */
   int32_t *remaining;              /* [ring] */
-  long long *final_id;             /* [ring] */
+  long long *final_id;             /* [ring], pinned host memory: the id of the batch that has become final in the slot */
+  int32_t *res;                    /* pinned host memory: what the pump reads when the slice has completed -- [0] survivors left,
+                                    * [j] entries of source j */
 };
 
 template <bool STAGING, class R, int OCC, class RIO = R>
@@ -572,7 +617,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
     const int j = threadIdx.x;
     const int c0 = *A.src[j].count, c = c0 < A.src[j].cap ? c0 : A.src[j].cap;
     const int old = atomicAdd(A.remaining + A.fresh_slot[j], c);
-    if (old + c == 0) __hip_atomic_store(A.final_id + A.fresh_slot[j], (long long)A.fresh_batch[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + c == 0) __hip_atomic_store(A.final_id + A.fresh_slot[j], (long long)A.fresh_batch[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const double *pk = nullptr;                      /* the entry this lane holds: its column in the source's rows, the rows' stride */
   int64_t lp = 0;
@@ -586,16 +631,25 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
       const double *pm = pk + (int64_t)(kParkRows + kTailInRows) * lp;
       const int64_t i = (int64_t)pm[0];
       const int slot = (int)pm[lp];
-      RIO *o = (RIO *)__double_as_longlong(pm[3 * lp]) + i;
+      RIO *ob = (RIO *)__double_as_longlong(pm[3 * lp]);
       RIO *tb = (RIO *)__double_as_longlong(pm[4 * lp]);
-      RIO *t = tb ? tb + i : nullptr;
       int32_t *st_arr = (int32_t *)__double_as_longlong(pm[5 * lp]), *it_arr = (int32_t *)__double_as_longlong(pm[6 * lp]);
       const int64_t l = (int64_t)pm[7 * lp];
-      S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, t != nullptr, ylo_user, yhi_user);
-      st_arr[i] = fin_status;
-      if (it_arr) it_arr[i] = S.iters + it_total;
-      const int old = atomicSub(A.remaining + slot, 1);
-      if (old == 1) __hip_atomic_store(A.final_id + slot, (long long)pm[2 * lp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      /* an entry is 70 numbers that have travelled through one or more queues: what it says about where its results go is checked
+       * before it is believed (a damaged one is reported to the host -- mpc_last_error -- instead of being written through) */
+      if (!(slot >= 0 && slot < A.ring && i >= 0 && i < l && ob && st_arr && l > 0)) {
+        __hip_atomic_store(A.res + 28, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.res + 29, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.res + 30, (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        RIO *o = ob + i;
+        RIO *t = tb ? tb + i : nullptr;
+        S.unpack([o, l](int q) { return OutRef<RIO, R>{o + q * l}; }, [t, l](int q) { return OutRef<RIO, R>{t + q * l}; }, t != nullptr, ylo_user, yhi_user);
+        st_arr[i] = fin_status;
+        if (it_arr) it_arr[i] = S.iters + it_total;
+        const int old = atomicSub(A.remaining + slot, 1);
+        if (old == 1) __hip_atomic_store(A.final_id + slot, (long long)pm[2 * lp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       fin = false;
     }
     if (!have && more) {
@@ -618,7 +672,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
         if (dpos >= 0) {
           double *dk = A.dst.park + dpos;
           const int64_t dl = A.dst.cap;
-          for (int q = 0; q < kTailRows; q++) dk[q * dl] = pk[q * lp];
+          rows_copy(dk, dl, pk, lp, 0, kTailRows);
           R *it_dst = (R *)A.dst.iter + (int64_t)(dpos >> 6) * M * FL::IT_SZ * 64 + (dpos & 63);
           for (int k = 0; k < M; ++k) {
             R rec[FL::IT_SZ];
@@ -673,17 +727,33 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
           double *dk = A.dst.park + dpos;
           const int64_t dl = A.dst.cap;
           S.park([dk, dl](int q) -> double & { return dk[q * dl]; }, attempt, it_total);
-          for (int q = kParkRows; q < kTailRows; q++) dk[q * dl] = pk[q * lp];
+          rows_copy(dk, dl, pk, lp, kParkRows, kTailRows);
           ws.stage_drain();
-          const int I = S.cur ? FL::IT1 : FL::IT0;
-          R *it_dst = (R *)A.dst.iter + (int64_t)(dpos >> 6) * M * FL::IT_SZ * 64 + (dpos & 63);
-          for (int k = 0; k < M; ++k)
-            for (int f = 0; f < FL::IT_SZ; f++) it_dst[(k * FL::IT_SZ + f) * 64] = ws.it(k, I, f);
+          tile_from_column<R>((R *)A.dst.iter + (int64_t)(dpos >> 6) * M * FL::IT_SZ * 64 + (dpos & 63), ws, S.cur ? FL::IT1 : FL::IT0, M);
           have = false;
         }
       }
     }
     ++wp;
+  }
+  /* The wave that leaves last closes the slice (no copies or memsets behind it on the stream: on a full device every one of those
+   * little launches waits for a free SIMD): it reports the counts to the host, and resets every counter for its next user --
+   * the list this slice has read is the next slice's destination, a fresh queue it has absorbed is free for its next batch,
+   * its own work counters serve the slice that takes this ring position again.  (Every wave's additions to the counters have
+   * returned before it arrives here: their results decided what it did.) */
+  if (threadIdx.x == 0) {
+    const int arrived = atomicAdd(A.done, 1);
+    if (arrived == (int)gridDim.x - 1) {
+      const int dc = __hip_atomic_load(A.dst.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(A.res, dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (int j = 1; j < A.n_src; j++) {
+        const int c = __hip_atomic_load(A.src[j].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.res + j, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      for (int j = 0; j < A.n_src; j++) __hip_atomic_store(A.src[j].count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(A.take, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(A.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -907,6 +977,13 @@ struct MpcHandle {
   double *d_run9 = nullptr;   /* run(): solve()'s 9 rows, caller's leading dimension */
   int64_t run9_ld = 0;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_rstat = nullptr, *d_counter = nullptr;
+  int64_t counter_seq = 0;    /* solve calls that used a counter block so far */
+  /* statistics are gathered when mpc_get_stats asks for them (a kernel per batch on the launch stream costs the serving loop a
+   * few per cent): what the most recent call wrote, and the event behind it */
+  const int32_t *st_status = nullptr, *st_iters = nullptr;
+  int64_t st_B = 0;
+  hipEvent_t st_ev = nullptr;
+  bool stats_pending = false;
   int inst_per_lane = 1;      /* MPC_INSTANCES_PER_LANE: waves = ceil(B / 64 / inst_per_lane) */
   int refill_min = 16, refill_wait = 8;   /* hand-over policy of the persistent kernel (MpcPhase), MPC_REFILL_MIN / MPC_REFILL_WAIT */
   int refill_floor = 0, refill_floor_f32 = 0;   /* MPC_REFILL_FLOOR / MPC_REFILL_FLOOR_F32 (the fp32 phase of a mixed solve) */
@@ -949,36 +1026,42 @@ struct MpcHandle {
     hipEvent_t ev = nullptr;
   };
   static constexpr int kBatchRecs = 1024;
-  struct SliceRes { int32_t src_count[kSliceMaxSrc]; int32_t dst_count; int32_t pad[2]; };
+  struct SliceRes { int32_t count[32]; };     /* [0]: survivors the slice left; [j]: entries of its source j */
+  static_assert(kSliceMaxSrc <= 32, "SliceRes");
   bool tail_ready = false;
   bool tail_double = true;     /* the solver of the tail slices: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
-  int tail_ring = 0, tail_waves = 128, tail_priority = 0, slice_passes = 24;
+  int tail_ring = 0, tail_waves = 128, tail_priority = 0, slice_passes = 32;
+  /* a slice's grid: a lane per survivor (they are the long chains: most use the slice's whole budget) and one per fresh_div fresh
+   * entries (an instance just over the cut needs a few more passes, so a lane works off several of them in turn) */
+  int fresh_div = 4;
   int64_t tail_cap = 0, surv_cap = 0, tail_min_batch = 4096;
   hipStream_t tail_stream = nullptr;
   MpcTailQ fq_dev[kFreshRing] = {}, surv_dev[2] = {};   /* device storage of the fresh queues and the two survivor lists */
-  int32_t *d_tcount = nullptr;   /* [kFreshRing + 2 + kSliceRing]: counts of the fresh queues, of the survivor lists, slice work counters */
+  int32_t *d_tcount = nullptr;   /* [kFreshRing + 2 + 2 kSliceRing]: counts of the fresh queues, of the survivor lists, slice work and exit counters */
   int32_t *d_remaining = nullptr;
-  long long *d_final = nullptr;
-  long long *h_final = nullptr;  /* pinned: [kSliceRing][tail_ring] the final flags as copied behind each slice */
-  SliceRes *h_res = nullptr;     /* pinned: [kSliceRing] */
+  long long *h_final = nullptr;  /* pinned: [tail_ring] the id of the batch that has become final in each slot (written by the slices) */
+  SliceRes *h_res = nullptr;     /* pinned: [kSliceRing], written by each slice's last wave */
   void *tail_ws = nullptr;
   TailSlot tslot[kTailMaxRing];
   FreshQ fq[kFreshRing];
   BatchRec *brec = nullptr;
   hipEvent_t slice_ev[kSliceRing] = {};
-  int slice_nabs[kSliceRing] = {};            /* fresh queues slice k % kSliceRing absorbed, and which */
-  int slice_abs[kSliceRing][kFreshRing] = {};
+  struct Absorbed { int fq; int slot; int64_t batch; };
+  int slice_nabs[kSliceRing] = {};            /* fresh queues slice k % kSliceRing absorbed, and which (queue, its batch and slot) */
+  Absorbed slice_abs[kSliceRing][kFreshRing] = {};
   int64_t n_slice = 0, n_slice_done = 0;      /* slices launched / retired */
   int64_t surv_last = 0;                      /* survivors the most recent retired slice left */
   int64_t fresh_avg = 64;                     /* running estimate of a batch's deferred instances (sizes a slice's grid) */
   int64_t n_not_final = 0;                    /* deferring batches not yet known to be final */
   int64_t n_throttled = 0;                    /* batches that ran without deferral because the survivors' list was filling up */
-  /* MpcParams.tail_cut = MPC_TAIL_AUTO: the cut follows the share of a batch that ends up deferred (a running mean over the
-   * batches retired so far, in 1/65536): above auto_hi the cut goes up a pass, below auto_lo down, at most every fourth batch.
-   * (The arithmetic of an instance does not depend on where it is carried on, so the cut changes timing only.) */
-  int auto_cut = 20, auto_since = 0;
+  /* MpcParams.tail_cut = MPC_TAIL_AUTO: the handle's own choice -- a cut at 20 passes for horizons up to N = 12, 24 beyond (the
+   * long horizons need more iterations), and a wave does not wait for its last 4 lanes (measured on the survey population:
+   * cuts of 16 ... 32 within 5 % of each other, 20 best; few 0 / 2 / 4 / 8: 43.4 / 43.8 / 44.7 / 44.8 M solves/s).  The arithmetic
+   * of an instance does not depend on where it is carried on, so these change timing only.  auto_share: running mean of the
+   * share of a batch that was handed over, in 1/65536 (mpc_tail_info). */
+  int tail_few = 4, tail_few_from = 8;        /* MPC_TAIL_FEW / MPC_TAIL_FEW_FROM (see MpcPhase.tail_few) */
+  int auto_cut = 20;
   int64_t auto_share = -1;
-  int64_t auto_lo = 262, auto_hi = 983;       /* 0.4 % and 1.5 % of a batch; MPC_TAIL_AUTO_LO / _HI in 1/65536 */
   int64_t batch_seq = 0;         /* id of the most recent batch (every solve call counts) */
   int64_t n_deferred = 0;        /* deferring batches so far: batch k of them uses slot k % tail_ring and fresh queue k % kFreshRing */
   double *d_tel = nullptr;       /* mpc_telemetry_batch_host: device staging, grown on demand */
@@ -1139,7 +1222,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->ws, ws_bytes)) != hipSuccess) return fail(e, "hipMalloc(workspace)");
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void **)&h->d_counter, kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&h->d_counter, kCounterRing * kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMemset(h->d_counter, 0, kCounterRing * kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMemset");
   if ((e = hipMalloc((void **)&h->d_stats, kStatWords * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   set_cuts(h, p);
@@ -1224,7 +1308,7 @@ extern "C" void mpc_destroy(MpcHandle *h) {
   if (h->d_tel) (void)hipFree(h->d_tel);
   if (h->tail_ready) (void)tail_drain(h);         /* stragglers still queued are finished: their batches' arrays may be read afterwards */
   if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
-  for (void *q : {(void *)h->d_tcount, (void *)h->d_remaining, (void *)h->d_final, h->tail_ws, (void *)h->surv_dev[0].park, h->surv_dev[0].iter,
+  for (void *q : {(void *)h->d_tcount, (void *)h->d_remaining, h->tail_ws, (void *)h->surv_dev[0].park, h->surv_dev[0].iter,
                   (void *)h->surv_dev[1].park, h->surv_dev[1].iter})
     if (q) (void)hipFree(q);
   for (int q = 0; q < kFreshRing; q++) {
@@ -1303,7 +1387,7 @@ static int tail_prepare(MpcHandle *h) {
   const size_t real_bytes = f32 ? sizeof(float) : sizeof(double);
   const int64_t tail_stride = f32 ? h->ws_stride_f32 : h->ws_stride_f64;
   h->tail_ring = P.tail_ring < 2 ? 2 : (P.tail_ring > kTailMaxRing ? kTailMaxRing : P.tail_ring);
-  int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 16;
+  int64_t cap = P.tail_capacity > 0 ? P.tail_capacity : h->max_batch / 8;
   if (cap < 256) cap = 256;
   if (cap > h->io_stride) cap = h->io_stride;
   h->tail_cap = (cap + 63) / 64 * 64;
@@ -1316,27 +1400,28 @@ static int tail_prepare(MpcHandle *h) {
   if (const char *e = getenv("MPC_TAIL_WAVES")) { h->tail_waves = atoi(e); if (h->tail_waves < 1) h->tail_waves = 1; }
   if (const char *e = getenv("MPC_TAIL_MIN_BATCH")) { h->tail_min_batch = atoll(e); if (h->tail_min_batch < 1) h->tail_min_batch = 1; }
   if (const char *e = getenv("MPC_SLICE_PASSES")) { h->slice_passes = atoi(e); if (h->slice_passes < 1) h->slice_passes = 1; }
-  if (const char *e = getenv("MPC_TAIL_AUTO_LO")) h->auto_lo = atoll(e);
-  if (const char *e = getenv("MPC_TAIL_AUTO_HI")) h->auto_hi = atoll(e);
-  if (const char *e = getenv("MPC_TAIL_AUTO_START")) { h->auto_cut = atoi(e); if (h->auto_cut < 8) h->auto_cut = 8; }
-  /* The tail stream's priority.  Stragglers are few waves with long chains: they should start as soon as a SIMD is free,
-   * so the default is the HIGH priority (MPC_TAIL_PRIORITY=low|normal|high to measure the others). */
+  if (const char *e = getenv("MPC_TAIL_FEW")) { h->tail_few = atoi(e); if (h->tail_few < 0) h->tail_few = 0; }
+  if (const char *e = getenv("MPC_TAIL_FEW_FROM")) { h->tail_few_from = atoi(e); if (h->tail_few_from < 1) h->tail_few_from = 1; }
+  if (const char *e = getenv("MPC_SLICE_FRESH_DIV")) { h->fresh_div = atoi(e); if (h->fresh_div < 1) h->fresh_div = 1; }
+  h->auto_cut = P.N <= 12 ? 20 : 24;
+  if (const char *e = getenv("MPC_TAIL_AUTO_CUT")) { h->auto_cut = atoi(e); if (h->auto_cut < 4) h->auto_cut = 4; }
+  /* The tail stream's priority: normal (MPC_TAIL_PRIORITY=low|normal|high to measure the others).  The slices are short and
+   * follow each other without a gap, so they need no head start; measured on the survey population, bulk launches on
+   * high-priority streams: tail stream high 44.7, normal or low 46.3 M solves/s. */
   int lo = 0, hi = 0;
   MPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      /* lo = least, hi = greatest priority (numerically smaller) */
-  int prio = hi;
+  int prio = 0;
   if (const char *e = getenv("MPC_TAIL_PRIORITY")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "normal") ? 0 : hi);
   h->tail_priority = prio;
   if (!h->tail_stream) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, prio));
-  const int n_counts = kFreshRing + 2 + kSliceRing;
+  const int n_counts = kFreshRing + 2 + 2 * kSliceRing;
   if (!h->d_tcount) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * n_counts));
   MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * n_counts));
   if (!h->d_remaining) MPC_HIP_CHECK(hipMalloc((void **)&h->d_remaining, sizeof(int32_t) * kTailMaxRing));
   MPC_HIP_CHECK(hipMemset(h->d_remaining, 0, sizeof(int32_t) * kTailMaxRing));
-  if (!h->d_final) MPC_HIP_CHECK(hipMalloc((void **)&h->d_final, sizeof(long long) * kTailMaxRing));
-  MPC_HIP_CHECK(hipMemset(h->d_final, 0, sizeof(long long) * kTailMaxRing));
-  if (!h->h_final) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_final, sizeof(long long) * kTailMaxRing * kSliceRing, hipHostMallocDefault));
+  if (!h->h_final) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_final, sizeof(long long) * kTailMaxRing, hipHostMallocDefault));
   if (!h->h_res) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_res, sizeof(MpcHandle::SliceRes) * kSliceRing, hipHostMallocDefault));
-  memset(h->h_final, 0, sizeof(long long) * kTailMaxRing * kSliceRing);
+  memset(h->h_final, 0, sizeof(long long) * kTailMaxRing);
   memset(h->h_res, 0, sizeof(MpcHandle::SliceRes) * kSliceRing);
   for (int q = 0; q < kFreshRing; q++) {
     const int rc = tail_alloc_queue(h, h->fq_dev[q], h->tail_cap, h->d_tcount + q);
@@ -1399,14 +1484,13 @@ static int tail_launch_slice(MpcHandle *h, bool force) {
     const int j = A.n_src++;
     A.src[j] = h->fq_dev[best]; A.fresh_slot[j] = F.slot; A.fresh_batch[j] = F.batch_id;
     F.state = 2; F.slice = k;
-    h->slice_abs[kr][h->slice_nabs[kr]++] = best;
-    est += h->fresh_avg;
+    h->slice_abs[kr][h->slice_nabs[kr]++] = MpcHandle::Absorbed{best, F.slot, F.batch_id};
+    est += (h->fresh_avg + h->fresh_div - 1) / h->fresh_div;
   }
-  A.budget = h->slice_passes;
-  A.take = h->d_tcount + kFreshRing + 2 + kr;
-  A.remaining = h->d_remaining; A.final_id = h->d_final;
-  MPC_HIP_CHECK(hipMemsetAsync(A.take, 0, sizeof(int32_t), ts));
-  MPC_HIP_CHECK(hipMemsetAsync(A.dst.count, 0, sizeof(int32_t), ts));
+  A.budget = h->slice_passes; A.ring = h->tail_ring;
+  h->h_res[kr].count[28] = 0;
+  A.take = h->d_tcount + kFreshRing + 2 + kr; A.done = h->d_tcount + kFreshRing + 2 + kSliceRing + kr;
+  A.remaining = h->d_remaining; A.final_id = h->h_final; A.res = h->h_res[kr].count;
   int64_t waves = (est + 63) / 64 + 1;
   if (waves > h->tail_waves) waves = h->tail_waves;
   if (waves < 1) waves = 1;
@@ -1421,11 +1505,8 @@ static int tail_launch_slice(MpcHandle *h, bool force) {
   else
     hipLaunchKernelGGL((mpc_tail_slice_kernel<true, double, 1>), dim3((unsigned)waves), dim3(kBlock), staging_lds_bytes<double>(), ts, h->params, A, (double *)h->tail_ws, tail_stride);
   MPC_HIP_CHECK(hipGetLastError());
-  /* what the pump reads when the slice has completed: the survivors it left, what each absorbed batch handed over, the final flags */
-  MpcHandle::SliceRes *res = h->h_res + kr;
-  MPC_HIP_CHECK(hipMemcpyAsync(&res->dst_count, A.dst.count, sizeof(int32_t), hipMemcpyDeviceToHost, ts));
-  for (int j = 1; j < A.n_src; j++) MPC_HIP_CHECK(hipMemcpyAsync(&res->src_count[j], A.src[j].count, sizeof(int32_t), hipMemcpyDeviceToHost, ts));
-  MPC_HIP_CHECK(hipMemcpyAsync(h->h_final + (size_t)kr * kTailMaxRing, h->d_final, sizeof(long long) * h->tail_ring, hipMemcpyDeviceToHost, ts));
+  /* (what the pump reads when the slice has completed -- the survivors it left, what each absorbed batch handed over, the final
+   * flags -- the slice's last wave writes into pinned host memory itself) */
   MPC_HIP_CHECK(hipEventRecord(h->slice_ev[kr], ts));
   ++h->n_slice;
   return MPC_OK;
@@ -1444,25 +1525,29 @@ static int tail_retire(MpcHandle *h, bool block, int *n_retired) {
     }
     block = false;
     const MpcHandle::SliceRes &res = h->h_res[kr];
-    h->surv_last = res.dst_count < h->surv_cap ? res.dst_count : h->surv_cap;
+    if (res.count[28] != 0) {
+      g_last_error = "tail slice: a damaged queue entry (slot " + std::to_string(res.count[29]) + ", instance " + std::to_string(res.count[30]) + ") was dropped";
+      return MPC_ERR_HIP;
+    }
+    h->surv_last = res.count[0] < h->surv_cap ? res.count[0] : h->surv_cap;
     for (int a = 0; a < h->slice_nabs[kr]; a++) {
-      MpcHandle::FreshQ &F = h->fq[h->slice_abs[kr][a]];
-      const int64_t c = res.src_count[1 + a] < h->tail_cap ? res.src_count[1 + a] : h->tail_cap;
-      if (h->tslot[F.slot].batch_id == F.batch_id) {
-        h->tslot[F.slot].deferred = c;
-        const int64_t Bs = h->tslot[F.slot].B > 0 ? h->tslot[F.slot].B : 1;
+      const MpcHandle::Absorbed &Ab = h->slice_abs[kr][a];
+      MpcHandle::FreshQ &F = h->fq[Ab.fq];
+      const int64_t c = res.count[1 + a] < h->tail_cap ? res.count[1 + a] : h->tail_cap;
+      /* (the queue may hold a later batch by now: a launch may take it again as soon as the slice that absorbed it has been
+       * ISSUED -- its stream waits for that slice -- which can be before this retirement) */
+      const bool still = F.state == 2 && F.batch_id == Ab.batch && F.slice == h->n_slice_done;
+      if (h->tslot[Ab.slot].batch_id == Ab.batch) {
+        h->tslot[Ab.slot].deferred = c;
+        const int64_t Bs = h->tslot[Ab.slot].B > 0 ? h->tslot[Ab.slot].B : 1;
         const int64_t share = c * 65536 / Bs;
         h->auto_share = h->auto_share < 0 ? share : (3 * h->auto_share + share) / 4;
-        if (h->params.tail_cut < 0 && ++h->auto_since >= 4) {
-          if (h->auto_share > h->auto_hi && h->auto_cut < 96) { ++h->auto_cut; h->auto_since = 0; }
-          else if (h->auto_share < h->auto_lo && h->auto_cut > 8) { --h->auto_cut; h->auto_since = 0; }
-        }
       }
       h->fresh_avg = (3 * h->fresh_avg + c + 3) / 4;
-      F.state = 0;
+      if (still) F.state = 0;
     }
     h->slice_nabs[kr] = 0;
-    const long long *fin = h->h_final + (size_t)kr * kTailMaxRing;
+    const volatile long long *fin = h->h_final;
     for (int q = 0; q < h->tail_ring; q++) {
       MpcHandle::TailSlot &S = h->tslot[q];
       if (S.batch_id != 0 && !S.final_ && fin[q] == (long long)S.batch_id) { S.final_ = true; --h->n_not_final; }
@@ -1617,7 +1702,17 @@ extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
   if (S.batch_id != batch_id) return MPC_OK;            /* long final: its slot holds a later batch */
   if (S.deferred >= 0) { *n = S.deferred; return MPC_OK; }
   for (int q = 0; q < kFreshRing; q++)
-    if (h->fq[q].batch_id == batch_id && h->fq[q].state != 0) {
+    if (h->fq[q].batch_id == batch_id && h->fq[q].state == 2) {       /* absorbed: the slice reports the count (and resets it) */
+      for (int guard = 0; guard < 64 && S.deferred < 0 && h->n_slice_done < h->n_slice; guard++) {
+        int nr = 0;
+        const int rc = tail_retire(h, true, &nr);
+        if (rc != MPC_OK) return rc;
+      }
+      *n = S.deferred >= 0 ? S.deferred : 0;
+      return MPC_OK;
+    }
+  for (int q = 0; q < kFreshRing; q++)
+    if (h->fq[q].batch_id == batch_id && h->fq[q].state == 1) {
       MPC_HIP_CHECK(hipEventSynchronize(h->fq[q].bulk));
       int32_t c = 0;
       MPC_HIP_CHECK(hipMemcpy(&c, h->fq_dev[q].count, sizeof(c), hipMemcpyDeviceToHost));
@@ -1639,7 +1734,7 @@ extern "C" int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n) {
 template <class RIO>
 static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const RIO *state, const RIO *coeffs, const RIO *yaw_lo,
                         const RIO *yaw_hi, const RIO *weights, RIO *out, RIO *traj, int32_t *status, int32_t *iters, hipStream_t s,
-                        const MpcPhase &tail) {
+                        const MpcPhase &tail, int32_t *cb, int32_t *zero_next) {
   const int64_t tiles = h->io_stride / 64;
   /* h->ws holds the handle's own layout; the phases need one workspace of each (each allocation on its own: a failure
    * leaves the handle usable for a retry, and mpc_destroy frees whatever exists) */
@@ -1654,12 +1749,11 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   float *ws32 = sizeof(RIO) == 4 ? (float *)h->ws : (float *)h->ws2;
   double *ws64 = sizeof(RIO) == 4 ? (double *)h->ws2 : (double *)h->ws;
   int32_t *it_out = iters ? iters : h->d_iters;
-  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, kCounterInts * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
   const unsigned waves = (unsigned)((B + kBlock - 1) / kBlock);
   MpcPhase T;
   memset(&T, 0, sizeof(T));
-  T.take = h->d_counter; T.n_out = h->d_counter + 1;
+  T.take = cb; T.n_out = cb + 1; T.zero_next = zero_next;
   T.out_inst = h->d_list; T.out_src = h->d_list + h->io_stride; T.out_park = h->d_park; T.ld_park = h->io_stride;
   T.refill_min = h->refill_min; T.refill_wait = h->refill_wait;
   T.promote_out = 1;
@@ -1672,7 +1766,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   MPC_HIP_CHECK(hipGetLastError());
   MpcPhase U;
   memset(&U, 0, sizeof(U));
-  U.take = h->d_counter + 2; U.n_out = h->d_counter + 3; U.n_in = h->d_counter + 1;
+  U.take = cb + 2; U.n_out = cb + 3; U.n_in = cb + 1;
   U.in_inst = h->d_list; U.in_src = h->d_list + h->io_stride; U.in_park = h->d_park; U.ld_park = h->io_stride;
   U.out_inst = h->d_list + 2 * h->io_stride; U.out_src = h->d_list + 3 * h->io_stride; U.out_park = h->d_park + (int64_t)kParkRows * h->io_stride;
   U.src_ws = ws32; U.src_tile_reals = h->ws_stride_f32;
@@ -1683,7 +1777,7 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.compact_cooldown = h->compact_cooldown;
   const unsigned waves2 = (waves + (unsigned)h->finish_div - 1) / (unsigned)h->finish_div;
   /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
-  U.tail_cut = tail.tail_cut; U.t_slot = tail.t_slot; U.t_batch = tail.t_batch; U.tq = tail.tq;
+  U.tail_cut = tail.tail_cut; U.t_slot = tail.t_slot; U.t_batch = tail.t_batch; U.tq = tail.tq; U.tail_few = tail.tail_few; U.tail_few_from = tail.tail_few_from;
   hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves2), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
   MPC_HIP_CHECK(hipGetLastError());
@@ -1705,7 +1799,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   }
   if (B < 0 || ld < B || ldo < B) { g_last_error = "ld < B"; return MPC_ERR_INVALID; }
   if (B > h->max_batch) { g_last_error = "B exceeds the handle's max_batch"; return MPC_ERR_INVALID; }
-  h->last_B = B; h->timed = false; h->have_stats = false;
+  h->last_B = B; h->timed = false; h->have_stats = false; h->stats_pending = false;
   ++h->batch_seq;
   if (B == 0) {                /* empty batch: nothing to read or write, pointers may be NULL; its id resolves as final */
     if (!h->brec) h->brec = new MpcHandle::BatchRec[MpcHandle::kBatchRecs];
@@ -1745,18 +1839,23 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     /* the fresh queue is taken again: the slice that absorbed its previous batch must have read it */
     MpcHandle::FreshQ &F = h->fq[fq_index];
     if (F.state == 1) { const int rc = tail_launch_slice(h, true); if (rc != MPC_OK) return rc; }
+    /* (its count is zero again: the slice's last wave has reset it) */
     if (F.state == 2) MPC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, h->slice_ev[F.slice % kSliceRing], 0));
-    MPC_HIP_CHECK(hipMemsetAsync(h->fq_dev[fq_index].count, 0, sizeof(int32_t), (hipStream_t)stream_));
   }
   const int n_cuts = (!defer && h->inst_per_lane == 1 && B >= h->two_phase_min) ? h->n_cuts : 0;
   auto tail_fields = [&](MpcPhase &T) {
     T.tail_cut = defer ? (h->params.tail_cut > 0 ? h->params.tail_cut : h->auto_cut) : 0; T.t_slot = slot_index; T.t_batch = h->batch_seq;
-    if (defer) T.tq = h->fq_dev[fq_index];
+    if (defer) { T.tq = h->fq_dev[fq_index]; T.tail_few = h->tail_few; T.tail_few_from = h->tail_few_from; }
   };
   /* behind the launch: the batch's record (what mpc_tail_wait / _poll / _stream_wait resolve its id with) */
+  int32_t *cb = h->d_counter + (h->counter_seq % kCounterRing) * kCounterInts;
+  int32_t *zero_next = h->d_counter + ((h->counter_seq + kCounterRing / 2) % kCounterRing) * kCounterInts;
+  ++h->counter_seq;
+  auto stats_later = [&](const int32_t *it_arr) { h->st_status = status; h->st_iters = it_arr; h->st_B = B; h->st_ev = rec->ev; h->stats_pending = true; };
   auto tail_done = [&]() -> int {
     rec->id = h->batch_seq; rec->kind = defer ? 1 : 0; rec->slot = slot_index;
-    if (!defer) { MPC_HIP_CHECK(hipEventRecord(rec->ev, s)); return MPC_OK; }
+    MPC_HIP_CHECK(hipEventRecord(rec->ev, s));
+    if (!defer) return MPC_OK;
     MpcHandle::FreshQ &F = h->fq[fq_index];
     F.batch_id = h->batch_seq; F.slot = slot_index; F.state = 1; F.slice = -1;
     MPC_HIP_CHECK(hipEventRecord(F.bulk, s));
@@ -1770,11 +1869,11 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     MpcPhase TT;
     memset(&TT, 0, sizeof(TT));
     tail_fields(TT);
-    const int rc = launch_mixed<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s, TT);
+    const int rc = launch_mixed<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters, s, TT, cb, zero_next);
     if (rc != MPC_OK) return rc;
     const int rt = tail_done();
     if (rt != MPC_OK) return rt;
-    if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
+    if (with_stats) stats_later(iters ? iters : h->d_iters);
     return MPC_OK;
   }
   if (n_cuts > 0) {
@@ -1784,17 +1883,17 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (!h->d_list) MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
   }
   if (h->lds_lanes > 0 && B <= h->lds_max_batch) {
+    --h->counter_seq;                              /* (this path uses no counters: the block stays clean for the next call) */
     MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
     const int rc = launch_lds<R>(h, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi, weights, out, traj, status, iters ? iters : h->d_iters, s);
     if (rc != MPC_OK) return rc;
     MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
     h->timed = true;
     { const int rt = tail_done(); if (rt != MPC_OK) return rt; }
-    if (with_stats) return record_stats(h, B, status, iters ? iters : h->d_iters, s);
+    if (with_stats) stats_later(iters ? iters : h->d_iters);
     return MPC_OK;
   }
   int32_t *it_out = iters ? iters : h->d_iters;
-  MPC_HIP_CHECK(hipMemsetAsync(h->d_counter, 0, kCounterInts * sizeof(int32_t), s));
   MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
   auto launch = [&](unsigned grid, void *wsp, const MpcPhase &tp) {
     constexpr int kOcc2 = sizeof(R) == 4 ? 2 : 1;
@@ -1814,9 +1913,10 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     MpcPhase T;
     memset(&T, 0, sizeof(T));          /* every switch a phase does not set is off */
     const int wr = p & 1, rd = wr ^ 1;
-    T.take = h->d_counter + 2 * p;
-    T.n_out = h->d_counter + 2 * p + 1;
-    T.n_in = p > 0 ? h->d_counter + 2 * (p - 1) + 1 : nullptr;
+    T.take = cb + 2 * p;
+    T.n_out = cb + 2 * p + 1;
+    T.n_in = p > 0 ? cb + 2 * (p - 1) + 1 : nullptr;
+    T.zero_next = p == 0 ? zero_next : nullptr;
     T.out_inst = h->d_list ? h->d_list + (int64_t)(2 * wr) * h->io_stride : nullptr;
     T.out_src = h->d_list ? h->d_list + (int64_t)(2 * wr + 1) * h->io_stride : nullptr;
     T.in_inst = h->d_list ? h->d_list + (int64_t)(2 * rd) * h->io_stride : nullptr;
@@ -1841,7 +1941,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
   h->timed = true;
   { const int rt = tail_done(); if (rt != MPC_OK) return rt; }
-  if (with_stats) return record_stats(h, B, status, it_out, s);
+  if (with_stats) stats_later(it_out);
   return MPC_OK;
 }
 
@@ -1941,6 +2041,47 @@ extern "C" int mpc_telemetry_batch_host(MpcHandle *h, int64_t B, int64_t ld, int
   if (rc != MPC_OK) return rc;
   MPC_HIP_CHECK(hipMemcpy2DAsync(cmd, sizeof(double) * ld, d_cmd, sizeof(double) * L, sizeof(double) * B, 2, hipMemcpyDeviceToHost, s));
   MPC_HIP_CHECK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipStreamSynchronize(s));
+  return MPC_OK;
+}
+
+/* MPC::run() for host arrays (the drop-in's B = 1 case, include/mpc_drop_in.hpp): one copy in, the three kernels of
+ * mpc_run_batch_device on the handle's own device and stream, one copy out; synchronises.  ptsx / ptsy are transformed in place
+ * like the reference does (MPC.cpp:329; mpc_main.cpp:189-190 relies on it). */
+extern "C" int mpc_run_batch_host(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx, double *ptsy,
+                                  double *out8, double *traj, int32_t *status, int32_t *iters, double *pre) {
+  if (!h) { g_last_error = "NULL handle"; return MPC_ERR_INVALID; }
+  if (B < 0 || ld < B || B > h->max_batch) { g_last_error = "bad B/ld"; return MPC_ERR_INVALID; }
+  if (npts < 3 || npts > mpc::RUN_MAX_PTS) { g_last_error = "npts must be 3..8"; return MPC_ERR_INVALID; }
+  if (h->params.precision != MPC_PRECISION_F64) { g_last_error = "run() entry points are fp64 only"; return MPC_ERR_INVALID; }
+  if (B == 0) { h->last_B = 0; return MPC_OK; }
+  if (!pose || !ptsx || !ptsy || !out8 || !status) { g_last_error = "NULL argument"; return MPC_ERR_INVALID; }
+  MPC_ON_DEVICE(h);
+  const int N = h->params.N;
+  const int64_t L = (B + 7) / 8 * 8;
+  const int64_t in_rows = 6 + 2 * npts, out_rows = 8 + 2 * N + 15;
+  const size_t need = sizeof(double) * (size_t)((in_rows + out_rows) * L) + sizeof(int32_t) * (size_t)(2 * L);
+  if (h->tel_bytes < need) {
+    if (h->d_tel) MPC_HIP_CHECK(hipFree(h->d_tel));
+    h->d_tel = nullptr; h->tel_bytes = 0;
+    MPC_HIP_CHECK(hipMalloc((void **)&h->d_tel, need));
+    h->tel_bytes = need;
+  }
+  double *d = h->d_tel, *d_px = d + 6 * L, *d_py = d_px + (int64_t)npts * L, *d_o8 = d + in_rows * L, *d_tr = d_o8 + 8 * L, *d_pre = d_tr + 2 * (int64_t)N * L;
+  int32_t *d_st = (int32_t *)(d_pre + 15 * L), *d_it = d_st + L;
+  hipStream_t s = h->stream;
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d, sizeof(double) * L, pose, sizeof(double) * ld, sizeof(double) * B, 6, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d_px, sizeof(double) * L, ptsx, sizeof(double) * ld, sizeof(double) * B, npts, hipMemcpyHostToDevice, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(d_py, sizeof(double) * L, ptsy, sizeof(double) * ld, sizeof(double) * B, npts, hipMemcpyHostToDevice, s));
+  const int rc = mpc_run_batch_device(h, B, L, npts, d, d_px, d_py, d_o8, traj ? d_tr : nullptr, d_st, d_it, d_pre, (void *)s);
+  if (rc != MPC_OK) return rc;
+  MPC_HIP_CHECK(hipMemcpy2DAsync(ptsx, sizeof(double) * ld, d_px, sizeof(double) * L, sizeof(double) * B, npts, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(ptsy, sizeof(double) * ld, d_py, sizeof(double) * L, sizeof(double) * B, npts, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpy2DAsync(out8, sizeof(double) * ld, d_o8, sizeof(double) * L, sizeof(double) * B, 8, hipMemcpyDeviceToHost, s));
+  if (traj) MPC_HIP_CHECK(hipMemcpy2DAsync(traj, sizeof(double) * ld, d_tr, sizeof(double) * L, sizeof(double) * B, 2 * N, hipMemcpyDeviceToHost, s));
+  if (pre) MPC_HIP_CHECK(hipMemcpy2DAsync(pre, sizeof(double) * ld, d_pre, sizeof(double) * L, sizeof(double) * B, 15, hipMemcpyDeviceToHost, s));
+  MPC_HIP_CHECK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+  if (iters) MPC_HIP_CHECK(hipMemcpyAsync(iters, d_it, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
   MPC_HIP_CHECK(hipStreamSynchronize(s));
   return MPC_OK;
 }
@@ -2067,8 +2208,14 @@ extern "C" int mpc_get_stats(MpcHandle *h, MpcBatchStats *st) {
   if (!h || !st) return MPC_ERR_INVALID;
   memset(st, 0, sizeof(*st));
   st->batch = h->last_B;
-  if (h->last_B == 0 || !h->have_stats) return MPC_OK;
+  if (h->last_B == 0 || !(h->have_stats || h->stats_pending)) return MPC_OK;
   MPC_ON_DEVICE(h);
+  if (h->stats_pending) {                      /* gathered now, behind the call's own launch (its arrays must still be there) */
+    MPC_HIP_CHECK(hipStreamWaitEvent(h->stream, h->st_ev, 0));
+    const int rc = record_stats(h, h->st_B, h->st_status, h->st_iters, h->stream);
+    if (rc != MPC_OK) return rc;
+    h->stats_pending = false;
+  }
   MPC_HIP_CHECK(hipEventSynchronize(h->ev_stats));
   unsigned long long acc[kStatWords];
   MPC_HIP_CHECK(hipMemcpy(acc, h->d_stats, sizeof(acc), hipMemcpyDeviceToHost));

@@ -118,6 +118,20 @@ class BatchedMPC:
             res["pre"].data_ptr() if want_pre else None, C.c_void_p(s.cuda_stream)), "mpc_run_batch_device")
         return res
 
+    def run_numpy(self, pose, ptsx, ptsy, want_traj=False):
+        """MPC::run() for host arrays (mpc_run_batch_host; B = 1 is what include/mpc_drop_in.hpp's MPC::run calls): pose [6,B],
+        ptsx / ptsy [npts,B] global waypoints.  Returns out8, status, iters, pre [15,B], the vehicle-frame waypoints and traj."""
+        import numpy as np
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        pose, px, py = f(pose), f(ptsx).copy(), f(ptsy).copy()
+        B, npts = pose.shape[1], px.shape[0]
+        out8 = np.empty((8, B)); pre = np.empty((15, B)); status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        traj = np.empty((2 * self.N, B)) if want_traj else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        check(library().mpc_run_batch_host(self._h, B, B, int(npts), p(pose), p(px), p(py), p(out8), p(traj), p(status), p(iters), p(pre)),
+              "mpc_run_batch_host")
+        return {"out8": out8, "status": status, "iters": iters, "pre": pre, "ptsx": px, "ptsy": py, "traj": traj}
+
     def telemetry_torch(self, tel, ptsx, ptsy, extra_latency=0.0, want_out8=False, stream=None):
         """The telemetry handler around run() (src/mpc_main.cpp:126-174) for a batch: tel [6,B] = x, y, psi,
         speed [mph], steering_angle (simulator sign), previous throttle.  Returns cmd [2,B] = (steering_angle,

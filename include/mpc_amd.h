@@ -134,11 +134,11 @@ typedef struct MpcParams {
    * is still running after tail_cut passes is handed to the handle's tail queue (status MPC_STATUS_PENDING) and the
    * launch ends; the queue is worked off by short tail slices on the handle's own tail stream while later batches run.
    * mpc_tail_wait / mpc_tail_poll / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
-  int32_t tail_cut;                /* default 0 = off; MPC_TAIL_AUTO (-1): the handle chooses the cut and keeps adjusting it so that
-                                    * about one instance in a hundred is handed over (results do not depend on the cut) */
+  int32_t tail_cut;                /* default 0 = off; MPC_TAIL_AUTO (-1): the handle's own choice (20 passes up to N = 12, 24 beyond;
+                                    * results do not depend on the cut) */
   int32_t tail_ring;               /* batches whose tails may be outstanding at once (2..512), default 128: a batch is final
                                     * only when its slowest straggler is, tens of milliseconds behind its launch */
-  int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 16.  A batch with more keeps the rest in its launch */
+  int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 8.  A batch with more keeps the rest in its launch */
   /* Mixed precision across phases.  MPC_PRECISION_F32 handles: f32_finish = 1 (default) runs the interior-point
    * iteration in fp32 until its barrier parameter has reached mixed_switch_mu and finishes every instance in fp64
    * (same state machine, tol instead of tol_f32, termination polish), fp32 at the ABI; 0 = the pure fp32 solver.
@@ -285,6 +285,10 @@ int mpc_solve_batch_host_f32(MpcHandle *h, int64_t B, int64_t ld, const float *s
 int mpc_run_batch_device(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx,
                          double *ptsy, double *out8, double *traj, int32_t *status, int32_t *iters,
                          double *pre, void *stream);
+/* The same for host arrays (all of them; ptsx / ptsy in: global, out: vehicle frame): one copy in, the kernels, one copy out, on the
+ * handle's own device and stream; synchronises.  B = 1 is MPC::run() itself (include/mpc_drop_in.hpp delegates to it). */
+int mpc_run_batch_host(MpcHandle *h, int64_t B, int64_t ld, int npts, const double *pose, double *ptsx, double *ptsy,
+                       double *out8, double *traj, int32_t *status, int32_t *iters, double *pre);
 /* The telemetry handler around run() (src/mpc_main.cpp:126-159, 171-174):
  *   tel [6][ld]   x, y, psi [rad], speed [mph], steering_angle (simulator sign), previous throttle command
  *   extra_latency seconds added to Config::lookahead (the handler's mean solve time, mpc_main.cpp:158)
@@ -364,7 +368,8 @@ int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n);   /* waits for
  * running mean of the deferred share of a batch in 1/65536 (-1: none retired yet) */
 int mpc_tail_info(const MpcHandle *h, int64_t *out12);
 int mpc_synchronize(MpcHandle *h);
-/* Statistics of the most recent mpc_solve_batch_* call (synchronises). */
+/* Statistics of the most recent mpc_solve_batch_* call: gathered when asked for, from the status / iters arrays that call
+ * wrote (they must still be there); waits for that call's launch. */
 int mpc_get_stats(MpcHandle *h, MpcBatchStats *stats);
 
 /* ---- diagnostics ------------------------------------------------------------ */

@@ -309,28 +309,34 @@ class MPC {                                                            /* MPC.h:
     return std::vector<double>(out, out + 9);
   }
 
-  /* MPC::run, MPC.h:54-55 / MPC.cpp:327-382.  ptsx/ptsy are transformed IN PLACE to the vehicle frame
-   * (mpc_main.cpp:189-190 relies on it).  Returns {x1,y1,psi1,v1,steer in [-1,1],accel,cte1,epsi1}. */
+  /* MPC::run, MPC.h:54-55 / MPC.cpp:327-382: the whole of it is the library's mpc_run_batch_host with B = 1 (frame transform,
+   * fit, bounds, solve, post-processing: the N1 kernels).  What the reference's run() leaves behind is kept: ptsx/ptsy transformed
+   * IN PLACE to the vehicle frame (mpc_main.cpp:189-190 relies on it), the fitted polynomial in roadGeometry, Config::yawLow /
+   * yawHigh (MPC.cpp:345-352) and the copy of the vehicle.  Returns {x1,y1,psi1,v1,steer in [-1,1],accel,cte1,epsi1}. */
   std::vector<double> run(Vehicle &veh, std::vector<double> &ptsx, std::vector<double> &ptsy,
                           std::vector<double> *x_trajectory = NULL, std::vector<double> *y_trajectory = NULL) {
-    const MpcParams p = Config::snapshot();
-    veh.globalToVehicle(ptsx, ptsy);
-    roadGeometry.setCenter(ptsx, ptsy, p.max_fit_order, p.max_fit_error);
+    ensure(1);
+    const int N = (int)Config::N, npts = (int)ptsx.size();
+    const double pose[6] = {veh.getX(), veh.getY(), veh.getOrientation(), veh.getVelocity(), veh.getSteering(), veh.getAcceleration()};
+    double out8[8], pre[15];
+    std::vector<double> traj(2 * N);
+    int32_t status = 0, iters = 0;
+    const int rc = mpc_run_batch_host(handle, 1, 1, npts, pose, ptsx.data(), ptsy.data(), out8, traj.data(), &status, &iters, pre);
+    if (rc != MPC_OK) throw std::string("mpc_run_batch_host failed: ") + mpc_last_error();
     vehicle = veh;
-    const double cte = roadGeometry.centerY(0);
-    const double epsi = -std::atan(roadGeometry.getPolynomial()[1]);
-    const double max_yaw_change = roadGeometry.computeOrientationChange(0, ptsx.back()) * (ptsx.back() - ptsx.front()) / ptsx.back();
-    const double max_speed = veh.computeYawChangeSpeedLimit(max_yaw_change, p.max_speed);
-    const double target_speed = veh.computeSpeedTarget(veh.getSteering(), max_speed);
-    if (max_yaw_change < 0) { Config::yawLow = max_yaw_change; Config::yawHigh = 0.1; }
-    else { Config::yawLow = -0.1; Config::yawHigh = max_yaw_change; }
-    std::vector<double> state = {0, 0, 0, veh.getVelocity(), cte, epsi};
-    std::vector<double> r = solve(state, target_speed, x_trajectory, y_trajectory);
-    double steer_angle = r[6];
-    if (std::fabs(max_yaw_change) > p.steer_adj_thresh) steer_angle += p.steer_adj_ratio * max_yaw_change;
-    const double accel = std::min(r[7], target_speed - veh.getVelocity());
-    const double steer_value = clamp(steer_angle / p.max_steering, -1.0, 1.0);
-    return {r[0], r[1], r[2], r[3], steer_value, accel, r[4], r[5]};
+    int nc = MPC_NCOEF;
+    while (nc > 3 && pre[6 + nc - 1] == 0.0) --nc;                      /* the fit's order (the rows are zero padded) */
+    roadGeometry.setPolynomial(std::vector<double>(pre + 6, pre + 6 + nc));
+    Config::yawLow = pre[11]; Config::yawHigh = pre[12];
+    if (status != MPC_STATUS_SUCCESS) {
+#ifdef EXIT_ON_IPOPT_FAILURE
+      throw std::string("Ipopt failed with ") + std::to_string(status);
+#else
+      std::cout << "Ipopt failed with " + std::to_string(status) << std::endl;
+#endif
+    }
+    if (x_trajectory) for (int i = 0; i < N; i++) { x_trajectory->push_back(traj[i]); y_trajectory->push_back(traj[N + i]); }
+    return std::vector<double>(out8, out8 + 8);
   }
 
   /* New: B independent instances in one call (host pointers, struct-of-arrays, see mpc_amd.h). */

@@ -752,6 +752,84 @@ def test_deferred_tails_finish_under_their_batchs_parameters(pkg, golden_dir, wa
             assert np.array_equal(o2[k].cpu().numpy(), ref["capped"][k], equal_nan=True), k
 
 
+def _busy(torch, stream, ms):
+    """Keeps `stream` busy for roughly `ms` milliseconds (a chain of matrix products), so that whatever is enqueued behind it has
+    provably not run when the host gets to its next line."""
+    with torch.cuda.stream(stream):
+        a = torch.ones((2048, 2048), device="cuda", dtype=torch.float32) * 1e-3
+        for _ in range(int(ms * 12)):
+            a = a @ a * 1e-3 + 1e-3
+    return a
+
+
+def test_tail_wait_resolves_every_batch_id(pkg, golden_dir, waypoints, torch_dev):
+    """mpc_tail_wait / mpc_tail_poll / mpc_tail_stream_wait for EVERY id: a batch whose ring slot has been taken again,
+    a batch that never deferred (below the size at which a handle defers), an empty batch, and an id the handle can no longer
+    resolve.  The outputs are prefilled with a sentinel and the solve stream is kept busy ahead of the launches, so a wait
+    that returned early would be seen: read back on a non-blocking stream, without any device-wide synchronisation."""
+    import torch
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 8192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=71)
+    w = pkg.scenarios.weight_sweep(B, params, seed=72, velocity_weights=(0.0, 1.0, 100.0))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev)
+    ins = [t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"])]
+    d_w = t(w)
+    SENT = 77
+    solve_stream = torch.cuda.Stream(device=torch_dev)
+    side = torch.cuda.Stream(device=torch_dev)
+    def read(x):
+        with torch.cuda.stream(side):
+            h = x.to("cpu", non_blocking=True)
+        side.synchronize()
+        return h.numpy()
+    p = params.copy(); p.tail_cut = 8; p.tail_ring = 2
+    with pkg.BatchedMPC(p, B, device=0) as mpc:
+        outs = [mpc.alloc_outputs(B, torch_dev, True) for _ in range(5)]
+        small = mpc.alloc_outputs(1500, torch_dev, True)
+        for o in outs + [small]:
+            o["status"].fill_(SENT)
+        torch.cuda.synchronize()
+        keep = _busy(torch, solve_stream, 40)
+        ids = []
+        with torch.cuda.stream(solve_stream):
+            for k in range(5):                                       # ring of 2: the slots of batches 1-3 are taken again
+                mpc.solve_torch(*ins, weights=d_w, outputs=outs[k]); ids.append(mpc.last_batch_id())
+            mpc.solve_torch(*[x[..., :1500] for x in ins], weights=d_w[:, :1500], outputs=small); id_small = mpc.last_batch_id()
+            mpc.solve_torch(*[x[..., :0].contiguous() for x in ins], weights=d_w[:, :0].contiguous(), outputs=mpc.alloc_outputs(0, torch_dev, True))
+            id_empty = mpc.last_batch_id()
+        assert ids == [1, 2, 3, 4, 5] and id_small == 6 and id_empty == 7
+        mpc.tail_wait(1)                                             # blocks until batch 1 is final, whatever became of its slot
+        st1 = read(outs[0]["status"])
+        assert not (st1 == SENT).any() and not (st1 == 5).any()
+        mpc.tail_wait(id_small)                                      # never deferred: final behind its own launch
+        sts = read(small["status"])
+        assert not (sts == SENT).any() and not (sts == 5).any()
+        assert mpc.tail_poll(id_small) and mpc.tail_poll(id_empty) and mpc.tail_poll(2)
+        mpc.tail_wait(id_empty)
+        consumer = torch.cuda.Stream(device=torch_dev)
+        mpc.tail_stream_wait(5, consumer)
+        with torch.cuda.stream(consumer):
+            n_bad = ((outs[4]["status"] == SENT) | (outs[4]["status"] == 5)).sum()
+        consumer.synchronize()
+        assert int(n_bad) == 0
+        with pytest.raises(pkg.MpcError):
+            mpc.tail_wait(99)                                        # not issued yet
+        mpc.tail_wait(0)
+        for k in range(5):
+            assert np.array_equal(read(outs[k]["status"]), read(outs[0]["status"]))
+        del keep
+    # an id older than the handle's record of its last 1 024 batches is refused, not silently "final"
+    with pkg.BatchedMPC(params, 64, device=0) as mpc:
+        o = mpc.alloc_outputs(64, torch_dev, False)
+        for _ in range(1030):
+            mpc.solve_torch(*[x[..., :64] for x in ins], outputs=o)
+        mpc.tail_wait(1029)
+        with pytest.raises(pkg.MpcError):
+            mpc.tail_wait(3)
+        torch.cuda.synchronize()
+
+
 def test_deferred_tails_stress_changing_batches_two_handles(pkg, golden_dir, waypoints, torch_dev):
     """Two handles on two streams, 40 batches of changing size (some below the size at which a handle defers at all) issued
     without a pause through a ring of 4 queue slots, consumers waiting through mpc_tail_stream_wait in issue order and out of
@@ -773,6 +851,7 @@ def test_deferred_tails_stress_changing_batches_two_handles(pkg, golden_dir, way
     consumer = torch.cuda.Stream(device=torch_dev)
     jobs = []
     try:
+        keep = [_busy(torch, st, 30) for st in streams]               # nothing below has run yet when the consumers start waiting
         for n in range(40):
             B = int(rng.choice([1500, 4096, 5000, 8192, 12345, 16384]))
             lo = int(rng.integers(0, BMAX - B + 1))
@@ -780,7 +859,9 @@ def test_deferred_tails_stress_changing_batches_two_handles(pkg, golden_dir, way
             sl = slice(lo, lo + B)
             ins = [t(b["state"][:, sl]), t(b["coeffs"][:, sl]), t(b["yaw_lo"][sl]), t(b["yaw_hi"][sl])]
             with torch.cuda.stream(s):
-                o = h.solve_torch(*ins, weights=t(w[:, sl]), want_traj=True)
+                o = h.alloc_outputs(B, torch_dev, True)
+                o["out"].fill_(-12345.0); o["status"].fill_(77)          # a consumer that ran early would sum the sentinel
+                h.solve_torch(*ins, weights=t(w[:, sl]), outputs=o)
             jobs.append((h, h.last_batch_id(), lo, B, o, ins))
         order = list(range(40))
         rng.shuffle(order)

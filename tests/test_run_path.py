@@ -152,6 +152,30 @@ def test_reference_snapshots_run_batch_device(pkg, golden_dir):
         assert np.max(np.abs(out8[[0, 1, 2, 3, 6, 7], i] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
 
 
+@pytest.mark.gpu
+def test_reference_snapshots_run_batch_host(pkg, golden_dir):
+    """mpc_run_batch_host with B = 1 -- the call include/mpc_drop_in.hpp's MPC::run() makes -- on the five snapshots: the run()
+    8-vector, the in-place transform of the waypoints (MPC.cpp:329) and the yaw bounds it leaves in Config (MPC.cpp:345-352)
+    against the oracle's MPC::run; and the five as one batch give the same numbers bit for bit."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
+    snaps = _snapshots()
+    col = lambda a: np.array(a, dtype=np.float64).reshape(-1, 1)
+    with pkg.BatchedMPC(params, 8, device=0) as mpc:
+        singles = [mpc.run_numpy(col(s["pose"]), col(s["ptsx"]), col(s["ptsy"]), want_traj=True) for s in snaps]
+        allb = mpc.run_numpy(np.array([s["pose"] for s in snaps]).T, np.array([s["ptsx"] for s in snaps]).T, np.array([s["ptsy"] for s in snaps]).T)
+    for i, (s, r) in enumerate(zip(snaps, singles)):
+        cfg = O.load_config("config-stable.json")
+        px, py = list(s["ptsx"]), list(s["ptsy"])
+        st, ref8, tx, ty, opre, _ = O.mpc_run(cfg, s["pose"], px, py)
+        assert st == 0 and r["status"][0] == 0
+        assert abs(r["out8"][4, 0] - ref8[4]) * params.max_steering < TOL_STEER and abs(r["out8"][5, 0] - ref8[5]) < TOL_ACCEL
+        assert np.max(np.abs(r["out8"][[0, 1, 2, 3, 6, 7], 0] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ
+        assert np.max(np.abs(r["ptsx"][:, 0] - np.array(px))) < 1e-9 and np.max(np.abs(r["ptsy"][:, 0] - np.array(py))) < 1e-9
+        assert abs(r["pre"][11, 0] - cfg.yaw_low) < 1e-12 and abs(r["pre"][12, 0] - cfg.yaw_high) < 1e-12
+        assert np.max(np.abs(r["traj"][:params.N, 0] - tx)) < TOL_TRAJ and np.max(np.abs(r["traj"][params.N:, 0] - ty)) < TOL_TRAJ
+        assert np.array_equal(allb["out8"][:, i], r["out8"][:, 0])
+
+
 # ---- N2: the telemetry handler around run() (src/mpc_main.cpp:126-174) ----------------------------------------------
 def _telemetry_from_pose(pose, rng):
     """Simulator-side telemetry whose handler-side pose is `pose` before latency compensation."""

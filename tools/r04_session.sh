@@ -6,11 +6,12 @@ S=${1:-a}
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 P=$OUT/r04${S}_progress.log
 echo "== start $S" | tee $P
-run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg "$@" > $OUT/r04${S}_$tag.json 2> $OUT/r04${S}_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
+run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --no-host-leg --full-json $OUT/r04${S}_$tag.json "$@" > $OUT/r04${S}_$tag.line 2> $OUT/r04${S}_$tag.err; echo "$tag exit=$?" | tee -a $P; python - <<PY | tee -a $P
 import json
 try:
     r = json.load(open("$OUT/r04${S}_$tag.json"))
-    print("   %-26s %8.3f M solves/s  %.3f ms/batch  iters %.2f max %d  status %s  kernel_ms %.3f tails %s" % ("$tag", r["value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["roofline"]["kernel_ms_avg"], r["config"]["deferred_tails"] if isinstance(r["config"]["deferred_tails"], str) else {k: r["config"]["deferred_tails"][k] for k in ("tail_launches", "instances_over_the_cut_in_the_last_batch", "waves_per_tail_launch")}))
+    t = r["config"]["deferred_tails"]
+    print("   %-26s %8.3f M solves/s (strict %.2f M)  %.3f ms/batch  iters %.2f max %d  status %s  kernel_ms %.3f  timing %s  tails %s" % ("$tag", r["value"] / 1e6, r["strict_value"] / 1e6, r["ms_per_step"], r["mean_iterations"], r["max_iterations"], {k: v for k, v in r["status_counts"].items() if v}, r["roofline"]["kernel_ms_avg"], [r["timing"][k] for k in ("first_timed_batch", "batches_in_the_window", "batches_outstanding_at_the_end")], t if isinstance(t, str) else {k: t[k] for k in ("tail_slices", "batches_deferred", "tail_cut_in_use", "batches_not_deferred_survivors_full")}))
 except Exception as e:
     print("   $tag: no result", e)
 PY
@@ -34,6 +35,26 @@ a)
   pmc n25_fetch FETCH_SIZE --steps 6 --warmup 4 $N25
   pmc n25_write WRITE_SIZE --steps 6 --warmup 4 $N25
   pmc n25_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --steps 6 --warmup 4 $N25
+  ;;
+b)   # round 4's tail slices: parity (bitwise) tests first, then the survey population
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "deferred or lane_compaction or phase_refill or native or test_cpp or edge_cases or batch_matches" > $OUT/r04b_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -8 $OUT/r04b_pytest.log
+  run filtered_c0 --steps 100 --population filtered --tail-cut 0
+  run survey_auto --steps 200
+  run survey_auto_k20 --steps 20
+  for c in 12 16 20 24 32; do run survey_c$c --steps 200 --tail-cut $c; done
+  for sp in 12 36; do MPC_SLICE_PASSES=$sp run survey_c20_sp$sp --steps 200 --tail-cut 20; done
+  MPC_TAIL_WAVES=32 run survey_c20_w32 --steps 200 --tail-cut 20
+  MPC_TAIL_PRIORITY=normal run survey_c20_np --steps 200 --tail-cut 20
+  run survey_c20_i3 --steps 200 --tail-cut 20 --inflight 3
+  ;;
+c)   # tail slices, tuned: the bench line with and without legs
+  export GPU_MAX_HW_QUEUES=8
+  run survey_auto_k20 --steps 20
+  run survey_auto_k200 --steps 200
+  run survey_auto_k1000 --steps 1000
+  run filtered_c0 --steps 100 --population filtered --tail-cut 0
+  ( time timeout -k 10 900 python bench.py --full-json $OUT/r04c_bench_full.json > $OUT/r04c_bench.line 2> $OUT/r04c_bench.err ) 2>&1 | tail -3 | tee -a $P; cat $OUT/r04c_bench.line | tee -a $P
   ;;
 esac
 echo done | tee -a $P
