@@ -103,8 +103,10 @@ def parse_args(argv=None):
                     help="instance generator: 'filtered' redraws what the reference's road model does not hold for (scenarios.py); "
                          "'survey' applies only SURVEY.md section 8d's rejection (compensated speed above Config::maxSpeed); "
                          "'unfiltered' keeps every draw with a finite fit")
-    ap.add_argument("--gather", choices=("root", "all"), default="root", help="the batch's one collective: gather to rank 0 (default; what "
-                    "north_star asks for) or all_gather_into_tensor to every rank")
+    ap.add_argument("--gather", choices=("direct", "root", "all"), default="direct", help="how a batch's results reach rank 0: 'direct' (default) -- "
+                    "every rank's solver writes them straight into rank 0's IPC-mapped buffers over xGMI, no collective in the data path (falls "
+                    "back to 'root' where the mapping is not available, and says so); 'root' -- one RCCL gather to rank 0 per batch group; 'all' -- "
+                    "all_gather_into_tensor to every rank")
     ap.add_argument("--gather-group", type=int, default=0, help="batches per collective (default 4 with more than one rank: a collective costs "
                     "the solve 8-10 %% by being there, whatever it carries; every batch is still gathered inside the timed region)")
     ap.add_argument("--gather-results-only", action="store_true", help="trajectories are computed but stay on their rank: only out[9], status, "
@@ -298,8 +300,8 @@ class Pipeline:
         n_slots = max(2 * g, 2 * self.nfl * self.depth) if not self.tail else max(int(outstanding) or self.nfl * int(tail_ring), 2 * g)
         tdt = torch.float32 if p.precision == pkg.PRECISION_F32 else torch.float64
         self.pg = pkg.sharding.PackedGather(B, p.N, want_traj, dev, dist if dist is not None else None, overlap=not args.no_overlap,
-                                            slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather == "root", gather_traj=not args.gather_results_only,
-                                            batches_per_collective=g)
+                                            slots=n_slots, dtype=tdt, force=args.force_collective, root_only=args.gather in ("root", "direct"), gather_traj=not args.gather_results_only,
+                                            batches_per_collective=g, direct=args.gather == "direct")
         self.nslots = self.pg.slots
         self.streams, self.gstream = None, None
         if stub is None:
@@ -470,7 +472,7 @@ def summarize(pkg, np, pipe, B, steps, elapsed):
                       "ring": info[0]["ring"], "capacity_per_batch": info[0]["capacity_per_batch"],
                       "waves_per_slice_max": info[0]["waves_per_tail_launch"], "passes_per_slice": info[0]["passes_per_slice"],
                       "batches_not_deferred_survivors_full": sum(i["batches_not_deferred_survivors_full"] for i in info),
-                      "tail_cut_in_use": info[0].get("tail_cut_in_use"),
+                      "tail_cut_in_use": info[0].get("tail_cut_in_use"), "queue_overflows": sum(i.get("queue_overflows", 0) for i in info),
                       "buffer_sets": pipe.nslots}
     return r, status, iters, outs
 
@@ -489,23 +491,23 @@ LEGS = {
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight")),
     "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 (every iteration in fp64: the "
                         "shipped default), SURVEY 8d's population, deferred tails, four batches in flight",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=60)),
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=150)),
     "configs_3_share_filtered": ("the same share drawn with the generator's rejection sampling",
-                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=-1, steps=60)),
+                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=-1, steps=150)),
     "configs_3_share_f32_start": ("the same share (SURVEY 8d's population) with MpcParams.f64_f32_start = MPC_F32_START_AUTO: horizons of 15 steps and more run their early "
                                   "iterations on the fp32 record (the long-horizon workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
-                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, population="survey", tail_cut=-1, steps=60,
+                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, population="survey", tail_cut=-1, steps=150,
                                        f32_start=True)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states (SURVEY 8d's population), fp32 mixed precision as shipped (fp32 "
                         "iterations down to the barrier parameter 2e-5, every instance finished in fp64), per-instance weight sweep (epsi / v incl. 0 / delta / a)",
-                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, population="survey", tail_cut=-1, steps=60, f32_refill=True)),
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300, f32_refill=True)),
     "configs_4_share_filtered": ("the same share drawn with the generator's rejection sampling",
-                                 dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=8, tail_cut=-1, steps=60, f32_refill=True)),
+                                 dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=-1, steps=300, f32_refill=True)),
     "configs_4_share_pure_fp32": ("the same share (SURVEY 8d's population) with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances)",
-                                  dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=60,
+                                  dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300,
                                        f32_pure=True)),
     "weights_sweep_f64": ("the fp64 solve of the configs[4] weight sweep (65 536 instances, SURVEY 8d's population): what the fp32 mode is to be compared with",
-                          dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=60)),
+                          dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300)),
 }
 
 
@@ -566,7 +568,7 @@ def extra_legs(args):
         if args.leg_tail_cut is not None:
             cmd += ["--leg-tail-cut", str(args.leg_tail_cut)]
         cmd += ["--tail-ring", str(args.tail_ring)]
-        env = dict(os.environ, GPU_MAX_HW_QUEUES=str(LEGS[name][1].get("hw_queues", 8)))
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=str(LEGS[name][1].get("hw_queues", 8)))     # (more than 8: two legs hung on the box)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         try:
@@ -740,6 +742,18 @@ def main():
                          torch.equal(g["status"][rank if dist is not None else 0], outs["status"]) and
                          (g["traj"] is None or torch.equal(g["traj"][rank if dist is not None else 0], outs["traj"])))
 
+    if dist is not None and getattr(pg, "direct", False) and world > 1:
+        # direct remote write: rank 0 checks that every rank's region of ITS buffers holds what that rank's solver says it wrote
+        mine = torch.stack([torch.nan_to_num(outs["out"].double()).sum(), outs["status"].double().sum(), outs["iters"].double().sum()]).to(dev)
+        alls = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(alls, mine)
+        if rank == 0:
+            ok = True
+            for r_ in range(world):
+                gr = pg.result(last)
+                got = torch.stack([torch.nan_to_num(gr["out"][r_].double()).sum(), gr["status"][r_].double().sum(), gr["iters"][r_].double().sum()])
+                ok = ok and bool(torch.equal(got.cpu(), alls[r_].cpu()))
+            gather_ok = ok
     if rank != 0:
         pipe.close()
         if dist is not None:
@@ -778,7 +792,7 @@ def main():
                    "mixed_precision": ("fp32 iterations to mu = %g, every instance finished in fp64" % params.mixed_switch_mu) if ((f32 and params.f32_finish) or
                                                                                                                                 (not f32 and params.f64_f32_start)) else "no",
                    "deferred_tails": summary.get("tails", "off"), "tail_cut": pipe.tail,
-                   "lane_compact": int(os.environ.get("MPC_LANE_COMPACT", params.lane_compact)) if B >= 8192 else 0,
+                   "lane_compact": int(os.environ.get("MPC_LANE_COMPACT", params.lane_compact if params.lane_compact >= 0 else (1 if params.N >= 15 else 2))) if B >= 8192 else 0,
                    # "survey": SURVEY.md 8d's population (only a compensated speed above Config::maxSpeed is redrawn); the leg "filtered"
                    # is the same workload with the generator's own rejection sampling (scenarios.py), rounds 1-3's headline
                    "population": args.population,
@@ -932,12 +946,25 @@ def emit(res, json_fd, args):
         hp = res["host_path"]
         out["host_path"] = [round(hp["solves_per_s_incl_pcie"]), round(hp["b1_latency_ms_median"], 3)]
     out["full"] = os.path.basename(path) if os.path.isabs(path) else path
+
+    def sig(x):                                                    # six significant digits are plenty for a summary line
+        if isinstance(x, float):
+            return float("%.6g" % x)
+        if isinstance(x, dict):
+            return {k: sig(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [sig(v) for v in x]
+        return x
+    out = sig(out)
     line = json.dumps(out, separators=(",", ":"))
-    if len(line) > 2040:                                           # the driver keeps 2 KB of tail: shed what is repeated in the full file
-        for k in ("cpu_baseline_same_algorithm", "cpu_baseline"):
-            if k in out and "sample" in out[k]:
-                out[k]["sample"] = short(out[k]["sample"], 24)
-        out["config"]["workload"] = short(out["config"]["workload"], 80)
+    for shed in (lambda: [out[k].__setitem__("sample", short(out[k]["sample"], 24)) for k in ("cpu_baseline_same_algorithm", "cpu_baseline") if k in out and "sample" in out[k]],
+                 lambda: out["config"].__setitem__("workload", short(out["config"]["workload"], 80)),
+                 lambda: out["config"].__setitem__("collective_mode", short(out["config"]["collective_mode"], 60)),
+                 lambda: out["config"].__setitem__("parallelism", short(out["config"]["parallelism"], 40)),
+                 lambda: out.pop("host_path", None), lambda: out["roofline"].pop("kernel", None)):
+        if len(line) <= 2040:                                      # the driver keeps 2 KB of tail: shed what is repeated in the full file
+            break
+        shed()
         line = json.dumps(out, separators=(",", ":"))
     sys.stdout.flush()
     os.write(json_fd, (line + "\n").encode())

@@ -354,7 +354,13 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
             }
             const bool from_scratch = T.promote_in && T.in_park[pos + 35 * T.ld_park] != 0.0;   /* the fp32 phase gave up on it */
             const int s0 = S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, !T.resume || from_scratch);
-            if (from_scratch) { S.begin(true); attempt = 0; it_total = (int)T.in_park[pos + 23 * T.ld_park] + (int)T.in_park[pos + 29 * T.ld_park]; passes = 0; have = true; }   /* (the fp32 phase's iterations count) */
+            if (T.promote_in && s0 != MPC_STATUS_SUCCESS) {
+              /* a start state that the fp32 set-up let through (outside the relaxed bounds by less than the fp32 spacing) and this
+               * solver's set-up rejects: the verdict of the single-phase solve, the start point reported */
+              S.start_point();
+              S.cur = 0; S.E.f = R(0.0);
+              it_total = 0; S.iters = 0; fin = true; fin_status = s0;
+            } else if (from_scratch) { S.begin(true); attempt = 0; it_total = (int)T.in_park[pos + 23 * T.ld_park] + (int)T.in_park[pos + 29 * T.ld_park]; passes = 0; have = true; }   /* (the fp32 phase's iterations count) */
             else if (T.resume) {
               /* bring the parked iterate over: the column (src wave, src lane) of phase A's workspace -> own column */
               const double *pk = T.in_park + pos;
@@ -1030,7 +1036,7 @@ struct MpcHandle {
   static_assert(kSliceMaxSrc <= 32, "SliceRes");
   bool tail_ready = false;
   bool tail_double = true;     /* the solver of the tail slices: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
-  int tail_ring = 0, tail_waves = 128, tail_priority = 0, slice_passes = 32;
+  int tail_ring = 0, tail_waves = 256, tail_priority = 0, slice_passes = 16;
   /* a slice's grid: a lane per survivor (they are the long chains: most use the slice's whole budget) and one per fresh_div fresh
    * entries (an instance just over the cut needs a few more passes, so a lane works off several of them in turn) */
   int fresh_div = 4;
@@ -1054,14 +1060,17 @@ struct MpcHandle {
   int64_t fresh_avg = 64;                     /* running estimate of a batch's deferred instances (sizes a slice's grid) */
   int64_t n_not_final = 0;                    /* deferring batches not yet known to be final */
   int64_t n_throttled = 0;                    /* batches that ran without deferral because the survivors' list was filling up */
-  /* MpcParams.tail_cut = MPC_TAIL_AUTO: the handle's own choice -- a cut at 20 passes for horizons up to N = 12, 24 beyond (the
-   * long horizons need more iterations), and a wave does not wait for its last 4 lanes (measured on the survey population:
+  int64_t n_overflow = 0;                     /* batches that handed over more than their fresh queue holds */
+  /* MpcParams.tail_cut = MPC_TAIL_AUTO: the handle's own choice -- it starts from a cut at 20 passes for horizons up to N = 12, 24
+   * beyond (the long horizons need more iterations), moves it out while more than 8 % of a batch are handed over (or a
+   * fresh queue overflows) and back while less than 1.5 % is; and a wave does not wait for its last 4 lanes (measured on the survey population:
    * cuts of 16 ... 32 within 5 % of each other, 20 best; few 0 / 2 / 4 / 8: 43.4 / 43.8 / 44.7 / 44.8 M solves/s).  The arithmetic
    * of an instance does not depend on where it is carried on, so these change timing only.  auto_share: running mean of the
    * share of a batch that was handed over, in 1/65536 (mpc_tail_info). */
   int tail_few = 4, tail_few_from = 8;        /* MPC_TAIL_FEW / MPC_TAIL_FEW_FROM (see MpcPhase.tail_few) */
-  int auto_cut = 20;
+  int auto_cut = 20, auto_base = 20;
   int64_t auto_share = -1;
+  int64_t auto_lo = 983, auto_hi = 5243;      /* 1.5 % and 8 % of a batch, in 1/65536 (MPC_TAIL_AUTO_LO / _HI) */
   int64_t batch_seq = 0;         /* id of the most recent batch (every solve call counts) */
   int64_t n_deferred = 0;        /* deferring batches so far: batch k of them uses slot k % tail_ring and fresh queue k % kFreshRing */
   double *d_tel = nullptr;       /* mpc_telemetry_batch_host: device staging, grown on demand */
@@ -1089,8 +1098,9 @@ static void set_cuts(MpcHandle *h, const MpcParams *p) {
   }
 }
 
-/* two phases per solve (fp32 iterations, fp64 finish)?  F32 handles: f32_finish; F64 handles: f64_f32_start = 1, or 2 (auto,
- * the default) from the horizon at which the workspace of a full device no longer lives in the Infinity Cache */
+/* two phases per solve (fp32 iterations, fp64 finish)?  F32 handles: f32_finish; F64 handles: f64_f32_start = 1, or 2
+ * (MPC_F32_START_AUTO; the default is 0 = off) from the horizon at which the workspace of a full device no longer lives in the
+ * Infinity Cache */
 static bool wants_mixed(const MpcParams *p) {
   if (p->precision == MPC_PRECISION_F32) return p->f32_finish != 0;
   return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && p->N >= MPC_F32_START_AUTO_N);
@@ -1111,7 +1121,7 @@ static int validate_params(const MpcParams *p) {
   if (p->max_iter < 1 || !(p->tol > 0)) { g_last_error = "bad max_iter/tol"; return MPC_ERR_INVALID; }
   if (p->tail_cut < MPC_TAIL_AUTO || p->tail_ring < 0 || p->tail_capacity < 0) { g_last_error = "bad tail_cut/tail_ring/tail_capacity"; return MPC_ERR_INVALID; }
   if (p->f64_f32_start < 0 || p->f64_f32_start > MPC_F32_START_AUTO) { g_last_error = "f64_f32_start must be 0 (off), 1 (on) or 2 (auto)"; return MPC_ERR_INVALID; }
-  if (p->lane_compact < 0 || p->lane_compact > 7) { g_last_error = "lane_compact must be 0 (off) .. 7"; return MPC_ERR_INVALID; }
+  if (p->lane_compact < MPC_LANE_COMPACT_AUTO || p->lane_compact > 7) { g_last_error = "lane_compact must be -1 (auto), 0 (off) .. 7"; return MPC_ERR_INVALID; }
   return MPC_OK;
 }
 
@@ -1243,7 +1253,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if (const char *e4 = getenv("MPC_REFILL_MIN")) { h->refill_min = atoi(e4); if (h->refill_min < 1) h->refill_min = 1; }
   if (const char *e5 = getenv("MPC_REFILL_WAIT")) { h->refill_wait = atoi(e5); if (h->refill_wait < 0) h->refill_wait = 0; }
   if (const char *e2 = getenv("MPC_INSTANCES_PER_LANE")) { h->inst_per_lane = atoi(e2); if (h->inst_per_lane < 1) h->inst_per_lane = 1; }
-  h->compact_gap = p->lane_compact;
+  h->compact_gap = p->lane_compact >= 0 ? p->lane_compact : (p->N >= 15 ? 1 : 2);
   if (const char *e9 = getenv("MPC_LANE_COMPACT")) { h->compact_gap = atoi(e9); h->compact_env = true; if (h->compact_gap < 0) h->compact_gap = 0; }
   if (const char *e10 = getenv("MPC_LANE_COMPACT_COOLDOWN")) { h->compact_cooldown = atoi(e10); if (h->compact_cooldown < 0) h->compact_cooldown = 0; }
   h->promote_buffer = p->f32_phase_refill != 0;
@@ -1280,7 +1290,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   }
   h->params = *p;
   set_cuts(h, p);
-  if (!h->compact_env) h->compact_gap = p->lane_compact;
+  if (!h->compact_env) h->compact_gap = p->lane_compact >= 0 ? p->lane_compact : (p->N >= 15 ? 1 : 2);
   if (!h->promote_env) h->promote_buffer = p->f32_phase_refill != 0;
   return MPC_OK;
 }
@@ -1393,7 +1403,7 @@ static int tail_prepare(MpcHandle *h) {
   h->tail_cap = (cap + 63) / 64 * 64;
   /* survivors: everything the outstanding batches may have alive at once.  A slice that finds the list full keeps the
    * instance until it is solved, and the solve calls stop deferring while the list is more than half full. */
-  int64_t sc = 4 * h->tail_cap;
+  int64_t sc = 8 * h->tail_cap;
   if (sc < 16384) sc = 16384;
   if (const char *e = getenv("MPC_TAIL_SURVIVORS")) { sc = atoll(e); if (sc < 64) sc = 64; }
   h->surv_cap = (sc + 63) / 64 * 64;
@@ -1403,8 +1413,10 @@ static int tail_prepare(MpcHandle *h) {
   if (const char *e = getenv("MPC_TAIL_FEW")) { h->tail_few = atoi(e); if (h->tail_few < 0) h->tail_few = 0; }
   if (const char *e = getenv("MPC_TAIL_FEW_FROM")) { h->tail_few_from = atoi(e); if (h->tail_few_from < 1) h->tail_few_from = 1; }
   if (const char *e = getenv("MPC_SLICE_FRESH_DIV")) { h->fresh_div = atoi(e); if (h->fresh_div < 1) h->fresh_div = 1; }
-  h->auto_cut = P.N <= 12 ? 20 : 24;
+  h->auto_cut = h->auto_base = P.N <= 12 ? 20 : 24;
   if (const char *e = getenv("MPC_TAIL_AUTO_CUT")) { h->auto_cut = atoi(e); if (h->auto_cut < 4) h->auto_cut = 4; }
+  if (const char *e = getenv("MPC_TAIL_AUTO_LO")) h->auto_lo = atoll(e);
+  if (const char *e = getenv("MPC_TAIL_AUTO_HI")) h->auto_hi = atoll(e);
   /* The tail stream's priority: normal (MPC_TAIL_PRIORITY=low|normal|high to measure the others).  The slices are short and
    * follow each other without a gap, so they need no head start; measured on the survey population, bulk launches on
    * high-priority streams: tail stream high 44.7, normal or low 46.3 M solves/s. */
@@ -1534,6 +1546,9 @@ static int tail_retire(MpcHandle *h, bool block, int *n_retired) {
       const MpcHandle::Absorbed &Ab = h->slice_abs[kr][a];
       MpcHandle::FreshQ &F = h->fq[Ab.fq];
       const int64_t c = res.count[1 + a] < h->tail_cap ? res.count[1 + a] : h->tail_cap;
+      /* the queue was too small for what the cut sent its way: the rest of that batch finished in its launch, stragglers included.
+       * MPC_TAIL_AUTO moves its cut out of the way (an explicit cut is the caller's: mpc_tail_info counts the overflows) */
+      if (res.count[1 + a] > h->tail_cap) { ++h->n_overflow; if (h->params.tail_cut < 0 && h->auto_cut < h->auto_base + 40) h->auto_cut += 4; }
       /* (the queue may hold a later batch by now: a launch may take it again as soon as the slice that absorbed it has been
        * ISSUED -- its stream waits for that slice -- which can be before this retirement) */
       const bool still = F.state == 2 && F.batch_id == Ab.batch && F.slice == h->n_slice_done;
@@ -1542,6 +1557,13 @@ static int tail_retire(MpcHandle *h, bool block, int *n_retired) {
         const int64_t Bs = h->tslot[Ab.slot].B > 0 ? h->tslot[Ab.slot].B : 1;
         const int64_t share = c * 65536 / Bs;
         h->auto_share = h->auto_share < 0 ? share : (3 * h->auto_share + share) / 4;
+        /* MPC_TAIL_AUTO follows the workload: a cut that sends more than 8 % of a batch to the slices is too early for this
+         * distribution of iteration counts (weight sweeps: mean 16-18 iterations, a fat tail) -- the slices would do the launches'
+         * work; one that sends next to nothing can come back towards the handle's base value */
+        if (h->params.tail_cut < 0) {
+          if (h->auto_share > h->auto_hi && h->auto_cut < h->auto_base + 40) h->auto_cut += 2;
+          else if (h->auto_share < h->auto_lo && h->auto_cut > h->auto_base) --h->auto_cut;
+        }
       }
       h->fresh_avg = (3 * h->fresh_avg + c + 3) / 4;
       if (still) F.state = 0;
@@ -1688,6 +1710,7 @@ extern "C" int mpc_tail_info(const MpcHandle *h, int64_t *out) {
   out[0] = h->n_deferred; out[1] = h->n_slice; out[2] = h->tail_ring; out[3] = h->tail_cap; out[4] = h->tail_waves;
   out[5] = h->tail_priority < 0 ? 1 : 0; out[6] = 1; out[7] = h->n_throttled; out[8] = h->slice_passes; out[9] = h->surv_last;
   out[10] = h->params.tail_cut > 0 ? h->params.tail_cut : (h->params.tail_cut < 0 ? h->auto_cut : 0); out[11] = h->auto_share;
+  out[12] = h->n_overflow;
   return MPC_OK;
 }
 
@@ -1777,7 +1800,8 @@ static int launch_mixed(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   U.compact_cooldown = h->compact_cooldown;
   const unsigned waves2 = (waves + (unsigned)h->finish_div - 1) / (unsigned)h->finish_div;
   /* deferred tails: the fp64 phase hands its stragglers over (the fp32 phase's chains end at kPromoteIterCap anyway) */
-  U.tail_cut = tail.tail_cut; U.t_slot = tail.t_slot; U.t_batch = tail.t_batch; U.tq = tail.tq; U.tail_few = tail.tail_few; U.tail_few_from = tail.tail_few_from;
+  /* (no early hand-over of a wave's last lanes here: the waves of this phase are partly filled by construction) */
+  U.tail_cut = tail.tail_cut; U.t_slot = tail.t_slot; U.t_batch = tail.t_batch; U.tq = tail.tq; U.tail_few = 0; U.tail_few_from = tail.tail_few_from;
   hipLaunchKernelGGL((mpc_solve_kernel<true, double, 1, RIO, float>), dim3(waves2), dim3(kBlock), staging_lds_bytes<double>(), s, h->params, B, ld, ldo, state,
                      coeffs, yaw_lo, yaw_hi, weights, out, traj, status, it_out, ws64, h->ws_stride_f64, U);
   MPC_HIP_CHECK(hipGetLastError());
@@ -1825,7 +1849,7 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     rc = tail_pump(h, false);
     if (rc != MPC_OK) return rc;
     /* the survivors' list is filling up (stragglers arrive faster than the slices finish them): this batch keeps its own */
-    if (2 * h->surv_last > h->surv_cap) { defer = false; ++h->n_throttled; }
+    if (2 * h->surv_last > h->surv_cap) { defer = false; ++h->n_throttled; if (h->params.tail_cut < 0 && h->auto_cut < h->auto_base + 40) h->auto_cut += 2; }
   }
   if (defer) {
     slot_index = (int)(h->n_deferred % h->tail_ring);
@@ -2157,10 +2181,8 @@ static int solve_host(MpcHandle *h, int64_t B, int64_t ld, const R *state, const
   constexpr int kInRows = 6 + MPC_NCOEF + 2 + MPC_NW;              /* 25 */
   constexpr int kIntRows = sizeof(R) == 8 ? 1 : 2;                 /* status and iters: 2 x int32 per instance */
   const int kOutRows = MPC_NOUT + 2 * N + kIntRows;                /* out, traj, status|iters (N is fixed per handle) */
-  if (!h->d_io) {
-    MPC_HIP_CHECK(hipMalloc((void **)&h->d_io, sizeof(R) * (kInRows + kOutRows) * S));
-    MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_io, sizeof(R) * (kInRows + kOutRows) * S, hipHostMallocDefault));
-  }
+  if (!h->d_io) MPC_HIP_CHECK(hipMalloc((void **)&h->d_io, sizeof(R) * (kInRows + kOutRows) * S));
+  if (!h->h_io) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_io, sizeof(R) * (kInRows + kOutRows) * S, hipHostMallocDefault));
   /* rows packed with leading dimension L (B rounded up to 16: 64-byte rows), so each direction is ONE copy */
   const int64_t L = (B + 15) / 16 * 16;
   const int in_rows = weights ? kInRows : kInRows - MPC_NW;

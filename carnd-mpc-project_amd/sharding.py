@@ -93,7 +93,7 @@ class PackedGather:
     """
 
     def __init__(self, b, N, want_traj, device, dist=None, group=None, overlap=True, slots=2, dtype=None, force=False,
-                 root_only=False, gather_traj=True, batches_per_collective=1):
+                 root_only=False, gather_traj=True, batches_per_collective=1, direct=False):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -117,6 +117,23 @@ class PackedGather:
         self.g = max(1, int(batches_per_collective))
         self.slots = (int(slots) + self.g - 1) // self.g * self.g
         self.is_cuda = torch.device(device).type == "cuda"
+        # direct=True (GPUs of one node): NO collective in the data path.  Rank 0 owns the gathered buffers, every other rank maps
+        # them (CUDA/HIP IPC: dmabuf handles, HSA_ENABLE_IPC_MODE_LEGACY=0) and its solver -- launches and tail slices alike -- writes
+        # its results straight into its own region of rank 0's memory over xGMI.  A batch is gathered the moment it is final.
+        self.direct = False
+        if direct and self.active and self.is_cuda:
+            try:
+                self._map_direct(device)
+                self.direct = True
+            except Exception as e:                              # never a silent change of path: `mode` says what ran and why
+                self.direct_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:120] if str(e) else "")
+        if self.direct:
+            self.work, self.ready, self.filled = [], [], []
+            self.collective_name = "direct remote write"
+            self.bytes_sent_per_rank = (self.res_rows + (2 * self.N if self.gather_traj else 0)) * self.b * (8 if self.dtype == torch.float64 else 4)
+            self.mode = ("direct: every rank's solver writes its results into rank 0's buffers (IPC-mapped, over xGMI); no collective in the "
+                         "data path" + ("" if self.gather_traj or not self.want_traj else ", results only (trajectories stay on their rank)"))
+            return
         self.res = torch.zeros((self.slots, self.res_rows, self.b), dtype=self.dtype, device=device)
         self.trj = torch.zeros((self.slots, 2 * self.N, self.b), dtype=self.dtype, device=device) if self.want_traj else None
         holds_full = self.active and (not self.root_only or self.rank == 0)
@@ -139,6 +156,41 @@ class PackedGather:
             self.mode += ", results only (trajectories stay on their rank)"
         if self.active and self.g > 1:
             self.mode += ", one collective per %d batches" % self.g
+        if direct and not self.direct and self.active:
+            self.mode += " (direct remote write not available: %s)" % getattr(self, "direct_error", "not a CUDA device")
+
+    def _map_direct(self, device):
+        torch, dist = self.torch, self.dist
+        shapes = {"res": (self.ws, self.slots, self.res_rows, self.b)}
+        if self.want_traj:
+            shapes["trj"] = (self.ws, self.slots, 2 * self.N, self.b)
+        full = {}
+        if self.ws == 1:
+            for k, shp in shapes.items():
+                full[k] = torch.zeros(shp, dtype=self.dtype, device=device)
+        else:
+            metas = [None]
+            if self.rank == 0:
+                for k, shp in shapes.items():
+                    full[k] = torch.zeros(shp, dtype=self.dtype, device=device)
+                torch.cuda.synchronize(device)
+                metas = [{k: t.untyped_storage()._share_cuda_() for k, t in full.items()}]
+            dist.broadcast_object_list(metas, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            if self.rank != 0:
+                for k, shp in shapes.items():
+                    m = list(metas[0][k])
+                    m[0] = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+                    st = torch.UntypedStorage._new_shared_cuda(*m)
+                    n = 1
+                    for d in shp:
+                        n *= d
+                    full[k] = torch.empty(0, dtype=self.dtype, device=device).set_(st, 0, (n,)).view(shp)
+            dist.barrier(group=self.group)
+        self.full_res = full["res"]
+        self.full_trj = full.get("trj") if self.gather_traj else None
+        self.res = full["res"][self.rank]
+        # trajectories that are not gathered stay in a buffer of the rank's own
+        self.trj = (full["trj"][self.rank] if self.gather_traj else torch.zeros((self.slots, 2 * self.N, self.b), dtype=self.dtype, device=device)) if self.want_traj else None
 
     def outputs(self, slot):
         """The tensors to hand to BatchedMPC.solve_torch(outputs=...): views into the packed buffers of `slot`."""
@@ -148,6 +200,8 @@ class PackedGather:
 
     def wait(self, slot):
         """Make the current stream wait for the collective that last carried `slot` (before the slot is written again)."""
+        if self.direct:
+            return
         gi = slot // self.g
         if self.work[gi]:
             for w in self.work[gi]:
@@ -199,7 +253,7 @@ class PackedGather:
                 h = (part.cpu() if part.is_cuda else part).contiguous()
                 if self.root_only:
                     parts = [torch.empty_like(h) for _ in range(self.ws)] if self.rank == 0 else None
-                    dist.gather(h, gather_list=parts, dst=0, group=self.group)
+                    dist.gather(h, gather_list=parts, dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
                     if self.rank == 0:
                         full[:, lo:hi].copy_(torch.stack(parts, dim=0))
                 else:
@@ -210,7 +264,7 @@ class PackedGather:
     def start(self, slot):
         """Hand the packed buffers of `slot` to the gather (call on the stream the solve that filled them was enqueued on, after
         it).  The collective goes out when the last slot of the group has been handed over."""
-        if not self.active:
+        if not self.active or self.direct:
             return
         if self.nccl and self.is_cuda:
             ev = self.torch.cuda.Event()
@@ -223,6 +277,8 @@ class PackedGather:
 
     def finish(self):
         """Flush partial groups and wait for every collective."""
+        if self.direct:
+            return
         if self.active:
             for gi in range(len(self.filled)):
                 if self.filled[gi] > 0:

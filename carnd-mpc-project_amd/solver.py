@@ -217,12 +217,12 @@ class BatchedMPC:
         return int(n.value)
 
     def tail_info(self):
-        a = (C.c_int64 * 12)()
+        a = (C.c_int64 * 13)()
         check(library().mpc_tail_info(self._h, a), "mpc_tail_info")
         return {"batches_deferred": int(a[0]), "tail_launches": int(a[1]), "ring": int(a[2]), "capacity_per_batch": int(a[3]),
                 "waves_per_tail_launch": int(a[4]), "tail_stream_high_priority": bool(a[5]), "tail_streams": int(a[6]),
                 "batches_not_deferred_survivors_full": int(a[7]), "passes_per_slice": int(a[8]), "survivors": int(a[9]),
-                "tail_cut_in_use": int(a[10]), "deferred_share": (int(a[11]) / 65536.0 if a[11] >= 0 else None)}
+                "tail_cut_in_use": int(a[10]), "deferred_share": (int(a[11]) / 65536.0 if a[11] >= 0 else None), "queue_overflows": int(a[12])}
 
     def synchronize(self):
         check(library().mpc_synchronize(self._h), "mpc_synchronize")

@@ -67,6 +67,7 @@ enum { MPC_F32_START_OFF = 0, MPC_F32_START_ON = 1, MPC_F32_START_AUTO = 2 };   
 #define MPC_F32_START_AUTO_N 15
 enum { MPC_PRECISION_F64 = 0, MPC_PRECISION_F32 = 1 };
 enum { MPC_TAIL_OFF = 0, MPC_TAIL_AUTO = -1 };   /* MpcParams.tail_cut */
+enum { MPC_LANE_COMPACT_AUTO = -1 };             /* MpcParams.lane_compact */
 
 /* Everything the reference reads from `struct Config` statics on this path
  * (src/utils/Config.h:66-177) AFTER Config::load() has applied its unit
@@ -134,8 +135,8 @@ typedef struct MpcParams {
    * is still running after tail_cut passes is handed to the handle's tail queue (status MPC_STATUS_PENDING) and the
    * launch ends; the queue is worked off by short tail slices on the handle's own tail stream while later batches run.
    * mpc_tail_wait / mpc_tail_poll / mpc_tail_stream_wait mark a batch final.  Results are bitwise those of the single launch. */
-  int32_t tail_cut;                /* default 0 = off; MPC_TAIL_AUTO (-1): the handle's own choice (20 passes up to N = 12, 24 beyond;
-                                    * results do not depend on the cut) */
+  int32_t tail_cut;                /* default 0 = off; MPC_TAIL_AUTO (-1): the handle's own choice (from 20 passes up to N = 12, 24 beyond; it moves
+                                    * the cut out while more than 8 % of a batch are handed over; results do not depend on the cut) */
   int32_t tail_ring;               /* batches whose tails may be outstanding at once (2..512), default 128: a batch is final
                                     * only when its slowest straggler is, tens of milliseconds behind its launch */
   int64_t tail_capacity;           /* deferred instances per batch; 0 = max_batch / 8.  A batch with more keeps the rest in its launch */
@@ -161,7 +162,8 @@ typedef struct MpcParams {
    * line is fetched as long as one of its 8 lanes still runs.  With lane_compact = g > 0 a wave whose running lanes are
    * spread over g more 8-lane groups than they need moves the ones outside its fullest groups into free lanes inside
    * them (launches of at least 8 192 instances, single-lane arithmetic unchanged: results are bitwise the same).
-   * Default 2; 0 = off. */
+   * Default MPC_LANE_COMPACT_AUTO: 2, and 1 for horizons of N >= 15, whose workspace (>= 360 KB per wave) is in HBM proper, where
+   * every line not fetched counts (configs[3] share: 6.90 -> 7.26 M solves/s); 0 = off. */
   int32_t lane_compact;
   /* Mixed precision, heavy-tailed workloads (weight sweeps: some instances spend the whole allowance of the fp32 phase
    * while most are handed over after 8-12 iterations).  With f32_phase_refill = 1 a lane of the fp32 phase hands its
@@ -362,11 +364,12 @@ int mpc_tail_wait(MpcHandle *h, int64_t batch_id);
 int mpc_tail_stream_wait(MpcHandle *h, int64_t batch_id, void *stream);
 int mpc_tail_flush(MpcHandle *h);
 int mpc_tail_pending(MpcHandle *h, int64_t batch_id, int64_t *n);   /* waits for the batch's own launch, then: how many it handed over */
-/* out12: batches deferred so far, tail slices so far, ring, capacity of a batch's fresh queue, waves per slice (upper bound), 1 if the
+/* out13: batches deferred so far, tail slices so far, ring, capacity of a batch's fresh queue, waves per slice (upper bound), 1 if the
  * tail stream has high priority, number of tail streams (1), batches that ran without deferral because the survivors' list was
  * filling up, passes per slice, survivors after the most recent retired slice, the cut in use (MPC_TAIL_AUTO: the current choice),
- * running mean of the deferred share of a batch in 1/65536 (-1: none retired yet) */
-int mpc_tail_info(const MpcHandle *h, int64_t *out12);
+ * running mean of the deferred share of a batch in 1/65536 (-1: none retired yet), batches that handed over more than their fresh
+ * queue holds (the rest finished in the launch; MPC_TAIL_AUTO then raises its cut) */
+int mpc_tail_info(const MpcHandle *h, int64_t *out13);
 int mpc_synchronize(MpcHandle *h);
 /* Statistics of the most recent mpc_solve_batch_* call: gathered when asked for, from the status / iters arrays that call
  * wrote (they must still be there); waits for that call's launch. */

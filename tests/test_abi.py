@@ -54,7 +54,7 @@ def test_params_from_json_match_oracle_config(pkg, golden_dir, name):
     assert list(p.steer_speeds)[:p.n_steer_speeds] == list(c.steer_speeds)[:c.n_steer_speeds]
     assert list(p.yaw_change_speeds)[:p.n_yaw_change_speeds] == list(c.yaw_change_speeds)[:c.n_yaw_change_speeds]
     assert p.branch_mode == 0 and p.precision == 0 and p.tol == 1e-8
-    assert p.lane_compact == 2 and p.tail_cut == 0 and p.f32_finish == 1 and p.f64_f32_start == 0 and p.f32_phase_refill == 0
+    assert p.lane_compact == -1 and p.tail_cut == 0 and p.f32_finish == 1 and p.f64_f32_start == 0 and p.f32_phase_refill == 0
 
 
 def test_params_errors(pkg, tmp_path):
@@ -83,7 +83,7 @@ def test_invalid_params_rejected(pkg, golden_dir):
     p = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"))
     h = C.c_void_p()
     for field, val in (("N", 2), ("N", 65), ("abi_version", 99), ("branch_mode", 1), ("precision", 7), ("max_iter", 0), ("lane_compact", 8),
-                       ("lane_compact", -1)):
+                       ("lane_compact", -2)):
         q = p.copy(); setattr(q, field, val)
         rc = pkg.library().mpc_create(C.byref(q), 0, 16, C.byref(h))
         assert rc in (-1, -4), (field, rc)

@@ -509,7 +509,7 @@ def test_lane_compaction_is_bitwise_identical(pkg, golden_dir, waypoints, torch_
         res["param 0"] = []
         res["param 2"] = []
         for (q, b, w, dt_) in cases:                       # the same through MpcParams.lane_compact (default 2)
-            assert q.lane_compact == 2
+            assert q.lane_compact == -1                    # MPC_LANE_COMPACT_AUTO: 2, or 1 from N = 15
             res["param 2"].append(solve(q, b, w, dt_))
             q0 = q.copy(); q0.lane_compact = 0
             res["param 0"].append(solve(q0, b, w, dt_))
@@ -795,7 +795,7 @@ def test_tail_wait_resolves_every_batch_id(pkg, golden_dir, waypoints, torch_dev
         with torch.cuda.stream(solve_stream):
             for k in range(5):                                       # ring of 2: the slots of batches 1-3 are taken again
                 mpc.solve_torch(*ins, weights=d_w, outputs=outs[k]); ids.append(mpc.last_batch_id())
-            mpc.solve_torch(*[x[..., :1500] for x in ins], weights=d_w[:, :1500], outputs=small); id_small = mpc.last_batch_id()
+            mpc.solve_torch(*[x[..., :1500].contiguous() for x in ins], weights=d_w[:, :1500].contiguous(), outputs=small); id_small = mpc.last_batch_id()
             mpc.solve_torch(*[x[..., :0].contiguous() for x in ins], weights=d_w[:, :0].contiguous(), outputs=mpc.alloc_outputs(0, torch_dev, True))
             id_empty = mpc.last_batch_id()
         assert ids == [1, 2, 3, 4, 5] and id_small == 6 and id_empty == 7
@@ -822,8 +822,9 @@ def test_tail_wait_resolves_every_batch_id(pkg, golden_dir, waypoints, torch_dev
     # an id older than the handle's record of its last 1 024 batches is refused, not silently "final"
     with pkg.BatchedMPC(params, 64, device=0) as mpc:
         o = mpc.alloc_outputs(64, torch_dev, False)
+        ins64 = [x[..., :64].contiguous() for x in ins]
         for _ in range(1030):
-            mpc.solve_torch(*[x[..., :64] for x in ins], outputs=o)
+            mpc.solve_torch(*ins64, outputs=o)
         mpc.tail_wait(1029)
         with pytest.raises(pkg.MpcError):
             mpc.tail_wait(3)

@@ -165,8 +165,8 @@ def test_reference_snapshots_run_batch_host(pkg, golden_dir):
         allb = mpc.run_numpy(np.array([s["pose"] for s in snaps]).T, np.array([s["ptsx"] for s in snaps]).T, np.array([s["ptsy"] for s in snaps]).T)
     for i, (s, r) in enumerate(zip(snaps, singles)):
         cfg = O.load_config("config-stable.json")
-        px, py = list(s["ptsx"]), list(s["ptsy"])
-        st, ref8, tx, ty, opre, _ = O.mpc_run(cfg, s["pose"], px, py)
+        _, px, py = O.run_pre(O.load_config("config-stable.json"), s["pose"], s["ptsx"], s["ptsy"])     # the waypoints in the vehicle frame
+        st, ref8, tx, ty, opre, _ = O.mpc_run(cfg, s["pose"], list(s["ptsx"]), list(s["ptsy"]))
         assert st == 0 and r["status"][0] == 0
         assert abs(r["out8"][4, 0] - ref8[4]) * params.max_steering < TOL_STEER and abs(r["out8"][5, 0] - ref8[5]) < TOL_ACCEL
         assert np.max(np.abs(r["out8"][[0, 1, 2, 3, 6, 7], 0] - ref8[[0, 1, 2, 3, 6, 7]])) < TOL_TRAJ

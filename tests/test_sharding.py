@@ -134,3 +134,23 @@ def test_packed_gather_single_process(pkg):
     r = pg.result(0)
     assert r["out"].shape == (1, 9, 16) and float(r["out"].sum()) == 3.0 * 9 * 16
     assert int(r["status"].sum()) == 32 and int(r["iters"].sum()) == 176
+
+
+@pytest.mark.gpu
+def test_direct_gather_two_processes_one_gpu():
+    """bench.py --gather direct with two ranks sharing the one GPU (--single-device; gloo carries the control messages, CUDA/HIP IPC
+    the data): rank 1's solver writes its results straight into rank 0's buffers, rank 0 checks its copy against rank 1's own sums."""
+    import json, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "4", "--warmup", "2",
+                        "--batch", "8192", "--gather", "direct", "--no-legs", "--no-cpu-baseline", "--no-host-leg", "--full-json", "/tmp/direct_gather_full.json"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    r = json.loads(line[-1])
+    assert r["n_gpus"] == 2 and r["config"]["gather_checked"] is True
+    assert r["config"]["collective_mode"].startswith("direct"), r["config"]["collective_mode"]
+    assert r["converged_fraction"] > 0.99 and r["value"] > 0

@@ -56,5 +56,56 @@ c)   # tail slices, tuned: the bench line with and without legs
   run filtered_c0 --steps 100 --population filtered --tail-cut 0
   ( time timeout -k 10 900 python bench.py --full-json $OUT/r04c_bench_full.json > $OUT/r04c_bench.line 2> $OUT/r04c_bench.err ) 2>&1 | tail -3 | tee -a $P; cat $OUT/r04c_bench.line | tee -a $P
   ;;
+d)   # the whole GPU suite, then slice length and the K = 20 line
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 1000 python -m pytest tests -m gpu -q -x > $OUT/r04d_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -6 $OUT/r04d_pytest.log
+  for sp in 12 16 32; do MPC_SLICE_PASSES=$sp run survey_sp$sp --steps 200; done
+  for k in 1 2 3; do run survey_k20_$k --steps 20 --warmup 5; done
+  ;;
+e)   # fixed tests, the default line, the one-rank collective rehearsal, N = 25
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "tail_wait_resolves or run_batch_host or lane_compaction or fp32_start or drop_in" > $OUT/r04e_pytest2.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -4 $OUT/r04e_pytest2.log
+  ( time timeout -k 10 900 python bench.py --steps 20 --warmup 5 --full-json $OUT/r04e_bench_full.json > $OUT/r04e_bench.line 2> $OUT/r04e_bench.err ) 2>&1 | tail -3 | tee -a $P; wc -c $OUT/r04e_bench.line | tee -a $P
+  run coll_root --steps 200 --force-collective
+  run coll_root_g1 --steps 200 --force-collective --gather-group 1
+  run coll_all --steps 200 --force-collective --gather all
+  run coll_none --steps 200
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  run n25_auto --steps 60 $N25
+  run n25_i6 --steps 60 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 6
+  MPC_LANE_COMPACT=2 run n25_lc2 --steps 60 $N25
+  MPC_TAIL_FEW=8 run n25_few8 --steps 60 $N25
+  MPC_TAIL_AUTO_CUT=20 run n25_c20 --steps 60 $N25
+  MPC_TAIL_AUTO_CUT=28 run n25_c28 --steps 60 $N25
+  run n25_f32start --steps 60 $N25 --f64-f32-start
+  ;;
+f)   # direct remote-write gather; the default line; rocprof of the headline
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "direct_gather or tail_wait_resolves" > $OUT/r04f_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -4 $OUT/r04f_pytest.log
+  run coll_direct --steps 200 --force-collective
+  run coll_none --steps 200
+  run coll_root --steps 200 --force-collective --gather root
+  MPC_TAIL_AUTO_CUT=16 run n25_c16_adapts --steps 60 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4
+  ( time timeout -k 10 900 python bench.py --steps 20 --warmup 5 --full-json $OUT/r04f_bench_full.json > $OUT/r04f_bench.line 2> $OUT/r04f_bench.err ) 2>&1 | tail -3 | tee -a $P; wc -c $OUT/r04f_bench.line | tee -a $P
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r04f_prof -o trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04f_prof_bench.json > /dev/null 2> $OUT/r04f_prof.err; echo "rocprof exit=$?" | tee -a $P
+  for c in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/r04f_pmc_$c -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04f_pmc_$c.json > /dev/null 2> $OUT/r04f_pmc_$c.err; echo "pmc $c exit=$?" | tee -a $P; done
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/r04f_pmc_sq -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04f_pmc_sq.json > /dev/null 2> $OUT/r04f_pmc_sq.err; echo "pmc sq exit=$?" | tee -a $P
+  cd $R
+  ;;
+g)   # the legs again with the adaptive cut
+  export GPU_MAX_HW_QUEUES=8
+  for l in ${LEGS_G:-configs_4_share configs_4_share_filtered configs_3_share_f32_start configs_3_share_filtered}; do
+    timeout -k 10 300 python bench.py --leg $l --tail-ring 128 > $OUT/r04g_$l.json 2> $OUT/r04g_$l.err; echo "$l exit=$?" | tee -a $P
+    python - <<PY | tee -a $P
+import json
+try:
+    l = json.load(open("$OUT/r04g_$l.json"))
+    print("   %-28s %7.2f M (strict %6.2f) iters %.2f max %d status %s tails %s" % ("$l", l["solves_per_s"]/1e6, l["strict_solves_per_s"]/1e6, l["mean_iterations"], l["max_iterations"], {a:b for a,b in l["status_counts"].items() if b}, {k: l["tails"][k] for k in ("tail_cut_in_use", "queue_overflows", "batches_not_deferred_survivors_full", "tail_slices")}))
+except Exception as e:
+    print("   $l: no result", e)
+PY
+  done
+  ;;
 esac
 echo done | tee -a $P
