@@ -222,6 +222,12 @@ struct TiledWorkspace {
    * The compiler does not see these as memory instructions; that only makes its own vmcnt waits more
    * conservative (vmcnt completes in order), and the sweeps order everything staged with explicit waits.
    * M0 is written by every statement and is in its clobber list: the compiler keeps nothing of its own there across one. */
+  /* cache policy of the staging loads (A/B builds: -DMPC_DMA_NT=1 marks them non-temporal) */
+#if defined(MPC_DMA_NT) && MPC_DMA_NT
+#define MPC_DMA_POLICY " nt"
+#else
+#define MPC_DMA_POLICY ""
+#endif
   template <int NG>
   MPC_HD void dma(int buf, int k, int I, int f0, int dst_group) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -232,18 +238,18 @@ struct TiledWorkspace {
       const gchar *src = row(k, f0 + (int)G * q0);
       constexpr int n = (NG - 0);
       if (q0 + 4 <= n)
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" MPC_DMA_POLICY "\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" MPC_DMA_POLICY "\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048" MPC_DMA_POLICY "\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" MPC_DMA_POLICY
                      :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else if (q0 + 3 == n)
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048"
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" MPC_DMA_POLICY "\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" MPC_DMA_POLICY "\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048" MPC_DMA_POLICY
                      :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else if (q0 + 2 == n)
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" MPC_DMA_POLICY "\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" MPC_DMA_POLICY
                      :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
       else
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" MPC_DMA_POLICY :: "v"(vo), "s"(src), "s"(m0v) : "memory", "m0");
     }
 #endif
   }

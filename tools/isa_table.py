@@ -11,7 +11,7 @@ txt = open(sp).read()
 T = {"d": "double", "f": "float"}
 print("| kernel <staging, solver reals, waves/SIMD, ABI reals[, source reals]> | VGPR + AGPR | scratch | waves/SIMD | code |")
 print("|---|---|---|---|---|")
-for m in re.finditer(r"^(_ZN12_GLOBAL__N_1\d+mpc_(solve|tail)_kernelILb([01])E([df])Li(\d)E([df])([df])?EE\w*):", txt, re.M):
+for m in re.finditer(r"^(_ZN12_GLOBAL__N_1\d+mpc_(solve|tail_slice)_kernelILb([01])E([df])Li(\d)E([df])([df])?EE\w*):", txt, re.M):
     K, kind, stg, r, occ, rio, rsrc = m.groups()
     mm = re.search(r"^" + re.escape(K) + r":.*?s_endpgm", txt, re.S | re.M)
     meta = dict(re.findall(r"; (NumVgprs|NumAgprs|ScratchSize|codeLenInByte|Occupancy)[:=]? *=? *(\d+)", txt[mm.end():mm.end() + 12000])[:5])
