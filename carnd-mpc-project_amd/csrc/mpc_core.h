@@ -1388,7 +1388,7 @@ struct Solver {
   /* the interior-point iteration                                         */
   /* ------------------------------------------------------------------ */
   enum { MPC_RUNNING = -1, MPC_PROMOTE = -2 };   /* PROMOTE: the fp32 phase of a mixed-precision solve hands the instance to fp64 */
-  enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3 };
+  enum { PH_EVAL0 = 0, PH_LS = 1, PH_DIR = 2, PH_BACKTRACK = 3, PH_REG = 4 };
   enum { kMaxPolish = 6 };
   enum { kPromoteIterCap = 16 };   /* mixed precision: the fp32 phase's allowance per instance (the bulk hands over after 8-12 iterations); one that uses it up is solved in fp64 from the start point */
   /* state of the interior-point loop (see step()) */
@@ -1412,6 +1412,8 @@ struct Solver {
   R out_prev;     /* the same of the step before (fp32 wants two quiet steps in a row) */
   R tol, out_tol;  /* "tol" of this precision (MpcParams.tol or tol_f32) and the polish's step tolerance */
   R alpha, alpha_l, alpha_z, dw_cur, theta_max, theta_min, dw_last;
+  R dw_try;        /* the regularisation the next backward sweep is tried with (phase REG) */
+  int reg_tries;
   R theta_k, phi_k, pth, pdp, amin;   /* line-search state */
 
   /* Solve from the start point that setup()/start_point() has written.
@@ -1515,6 +1517,10 @@ struct Solver {
    *   LS        least-squares multiplier start (W&B section R(3.6), IPOPT default): one Riccati pass
    *             with identity Hessian; estimates above constr_mult_init_max = 1000 are discarded
    *   DIR       convergence test, barrier update, search direction, first trial of the line search
+   *   REG       the same search direction again with the next regularisation (the Riccati sweep found the wrong inertia): a
+   *             pass of its own, so that the other 63 lanes of the wave do not stand still while one instance repeats its
+   *             backward sweep (1.6 times per pass on the hard instances of the survey population: a tenth of the waves
+   *             has one)
    *   BACKTRACK further trials of the same line search
    * Returns MPC_RUNNING, or the final status of this attempt. */
   MPC_HD int step() {
@@ -1522,7 +1528,8 @@ struct Solver {
      * its answers lose against fp64 is mostly the barrier's pull on weakly active bounds (mu/z), not rounding, while
      * slacks of active bounds (mu/z ~ 1e-6 on a ~ 4.47) must stay above a few ulp */
     const R mu_floor = sizeof(R) == 8 ? tol / R(10.0) : tol / R(25.0);
-    if (phase == PH_LS || phase == PH_DIR) {
+    if (phase == PH_LS || phase == PH_DIR || phase == PH_REG) {
+      if (phase != PH_REG) { dw_try = R(0.0); reg_tries = 0; }
       if (phase == PH_DIR) {
         iters = iter;
         const R E0 = kkt_error(E, R(0.0));
@@ -1561,16 +1568,21 @@ struct Solver {
 #endif
       }
       lsm = (phase == PH_LS);
-      /* search direction with inertia correction, W&B section 3.1 */
-      R dw = R(0.0);
-      int tries = 0;
+      /* search direction with inertia correction, W&B section 3.1: ONE backward sweep per pass; the wrong inertia sends the
+       * instance round again with the next regularisation (phase REG) */
+      R dw = dw_try;
       bool okb = true;
-      while (!backward(dw)) {
-        if (lsm) { okb = false; break; }
-        if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
-        else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
-        if (dw > IC::dw_max || ++tries > 100) { promote_clean = false; return (kCanPromote && promote_mu > R(0.0)) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH; }
+      if (!backward(dw)) {
+        if (lsm) okb = false;
+        else {
+          if (dw == R(0.0)) dw = (dw_last == R(0.0)) ? IC::dw_0 : mpc_max(IC::dw_min, IC::kw_minus * dw_last);
+          else dw *= (dw_last == R(0.0)) ? IC::kw_plus_bar : IC::kw_plus;
+          if (dw > IC::dw_max || ++reg_tries > 100) { promote_clean = false; return (kCanPromote && promote_mu > R(0.0)) ? (int)MPC_PROMOTE : (int)MPC_STATUS_LINESEARCH; }
+          dw_try = dw; phase = PH_REG;
+          return MPC_RUNNING;
+        }
       }
+      if (phase == PH_REG) phase = PH_DIR;
       if (okb) forward();
       dw_cur = dw;
       if (phase == PH_LS) {

@@ -549,8 +549,9 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           pk[5 * lp] = __longlong_as_double((long long)status); pk[6 * lp] = __longlong_as_double((long long)iters);
           pk[7 * lp] = (double)ldo;
           ws.stage_drain();                          /* the trial sweep's stores of this wave have landed */
-          const int I = S.cur ? FL::IT1 : FL::IT0, M = P.N - 1;
-          tile_from_column<R>((R *)T.tq.iter + (int64_t)(pos >> 6) * M * FL::IT_SZ * 64 + (pos & 63), ws, I, M);
+          /* (copied by the lane itself: the whole wave copying a deferring lane's column -- two round trips instead of twenty --
+           * was built in round 4 and measured: no change in the launch's duration, 2.67 ms either way) */
+          tile_from_column<R>((R *)T.tq.iter + (int64_t)(pos >> 6) * (P.N - 1) * FL::IT_SZ * 64 + (pos & 63), ws, S.cur ? FL::IT1 : FL::IT0, P.N - 1);
           status[i] = MPC_STATUS_PENDING;
           if (iters) iters[i] = S.iters + it_total;
           have = false;                              /* the lane takes its next instance at the next hand-over */
@@ -1067,6 +1068,7 @@ struct MpcHandle {
    * cuts of 16 ... 32 within 5 % of each other, 20 best; few 0 / 2 / 4 / 8: 43.4 / 43.8 / 44.7 / 44.8 M solves/s).  The arithmetic
    * of an instance does not depend on where it is carried on, so these change timing only.  auto_share: running mean of the
    * share of a batch that was handed over, in 1/65536 (mpc_tail_info). */
+  int64_t hold_batches = 0;
   int tail_few = 4, tail_few_from = 8;        /* MPC_TAIL_FEW / MPC_TAIL_FEW_FROM (see MpcPhase.tail_few) */
   int auto_cut = 20, auto_base = 20;
   int64_t auto_share = -1;
@@ -1410,6 +1412,7 @@ static int tail_prepare(MpcHandle *h) {
   if (const char *e = getenv("MPC_TAIL_WAVES")) { h->tail_waves = atoi(e); if (h->tail_waves < 1) h->tail_waves = 1; }
   if (const char *e = getenv("MPC_TAIL_MIN_BATCH")) { h->tail_min_batch = atoll(e); if (h->tail_min_batch < 1) h->tail_min_batch = 1; }
   if (const char *e = getenv("MPC_SLICE_PASSES")) { h->slice_passes = atoi(e); if (h->slice_passes < 1) h->slice_passes = 1; }
+  if (const char *e = getenv("MPC_TAIL_HOLD_BATCHES")) h->hold_batches = atoll(e);
   if (const char *e = getenv("MPC_TAIL_FEW")) { h->tail_few = atoi(e); if (h->tail_few < 0) h->tail_few = 0; }
   if (const char *e = getenv("MPC_TAIL_FEW_FROM")) { h->tail_few_from = atoi(e); if (h->tail_few_from < 1) h->tail_few_from = 1; }
   if (const char *e = getenv("MPC_SLICE_FRESH_DIV")) { h->fresh_div = atoi(e); if (h->fresh_div < 1) h->fresh_div = 1; }
@@ -1593,6 +1596,10 @@ static int tail_pump(MpcHandle *h, bool block) {
   int n = 0;
   int rc = tail_retire(h, block && h->n_slice_done < h->n_slice, &n);
   if (rc != MPC_OK) return rc;
+  /* (measurement aid: MPC_TAIL_HOLD_BATCHES=n keeps the slices back until n batches have deferred, so that the launches can be
+   * timed with and without slices beside them; a blocking call releases them) */
+  if (!block && h->hold_batches > 0 && h->n_deferred < h->hold_batches) return MPC_OK;
+  h->hold_batches = 0;
   for (int turn = 0; turn < 2 && h->n_slice - h->n_slice_done < 2; turn++) {
     const bool in_flight = h->n_slice_done < h->n_slice;
     const bool filled = tail_has_filled(h);

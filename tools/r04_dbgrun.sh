@@ -1,13 +1,8 @@
-# same-box A/B: staging loads non-temporal (gpurun_in/libmpc_amd_nt.so) against the shipped build, N = 25 share and the headline
 cd $GRAFT_REPO_ROOT; export GPU_MAX_HW_QUEUES=8
-cp carnd-mpc-project_amd/lib/libmpc_amd.so /tmp/libmpc_keep.so
-one() { timeout -k 10 200 python bench.py --no-legs --no-cpu-baseline --no-host-leg --full-json /tmp/ab.json "$@" > /dev/null 2>/tmp/ab.err; python -c "
-import json; r=json.load(open('/tmp/ab.json')); print('   %.3f M solves/s  kernel_ms %.3f' % (r['value']/1e6, r['roofline']['kernel_ms_avg']))"; }
-for round in 1 2; do
-  for lib in plain nt; do
-    if [ $lib = nt ]; then cp gpurun_in/libmpc_amd_nt.so carnd-mpc-project_amd/lib/libmpc_amd.so; else cp /tmp/libmpc_keep.so carnd-mpc-project_amd/lib/libmpc_amd.so; fi
-    echo "== round $round $lib: N=25 share (survey), 150 steps"; one --steps 150 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4
-    echo "== round $round $lib: headline (survey), 200 steps"; one --steps 200
-  done
+timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "deferred or lane_compaction or phase_refill or tail_wait or batch_matches or leave_the_central or multi_phase or staged_and_plain" 2>&1 | tail -3
+for rep in 1 2; do
+MPC_TAIL_HOLD_BATCHES=20 timeout -k 5 100 python tools/hold_test.py --tail-cut 20 2>&1 | tail -1
+MPC_TAIL_HOLD_BATCHES=20 timeout -k 5 100 python tools/hold_test.py --tail-cut 20 --population filtered 2>&1 | tail -1
 done
-cp /tmp/libmpc_keep.so carnd-mpc-project_amd/lib/libmpc_amd.so
+for k in 1 2; do timeout -k 10 200 python bench.py --no-legs --no-cpu-baseline --no-host-leg --steps 200 --full-json /tmp/x.json > /dev/null 2>&1; python -c "
+import json; r=json.load(open('/tmp/x.json')); print('headline survey K=200: %.2f M  kernel_ms %.3f' % (r['value']/1e6, r['roofline']['kernel_ms_avg']))"; done
