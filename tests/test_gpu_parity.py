@@ -123,6 +123,27 @@ def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torc
     assert 0.2 < rp["iters"].mean() - r["iters"].mean() < 1.0
 
 
+def test_acceptable_level_termination_matches_oracle(pkg, golden_dir, waypoints, torch_dev):
+    """MPC_STATUS_ACCEPTABLE on the device (IPOPT's acceptable_tol / acceptable_iter, include/mpc_amd.h): with an acceptable level of
+    1e-3 and two iterates in a row most instances of a batch stop a step or two short of convergence -- the same instances, after the
+    same number of iterations, at the same point as in the oracle; with IPOPT's defaults nothing changes; the statistics count them."""
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    B = 192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=31)
+    plain = gpu_solve(pkg, params, b, torch_dev)
+    assert (plain["status"] == 0).all()
+    q = params.copy(); q.acceptable_tol = 1e-3; q.acceptable_iter = 2
+    with pkg.BatchedMPC(q, B, device=0) as mpc:
+        r = gpu_solve(pkg, q, b, torch_dev, mpc=mpc)
+        st = mpc.stats()
+    acc = r["status"] == 6
+    assert acc.sum() > B // 2 and set(np.unique(r["status"])) <= {0, 6}
+    assert st.n_acceptable == acc.sum() and st.n_success == (~acc).sum() and st.n_numeric == 0
+    ref = oracle_solve_batch(O.load_config("config-fast.json"), b, range(B), opt=O.default_options(acceptable_tol=1e-3, acceptable_iter=2))
+    assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"])
+    assert_parity(r["out"], ref["out"], r["traj"], ref["traj"], "acceptable level")
+
+
 def test_per_instance_weights_match_oracle(pkg, golden_dir, waypoints, torch_dev):
     """BASELINE.json configs[4] at test size (fp64): per-instance weight sweep."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
