@@ -171,20 +171,55 @@ class PackedGather:
         else:
             metas = [None]
             if self.rank == 0:
-                for k, shp in shapes.items():
-                    full[k] = torch.zeros(shp, dtype=self.dtype, device=device)
-                torch.cuda.synchronize(device)
-                metas = [{k: t.untyped_storage()._share_cuda_() for k, t in full.items()}]
+                try:
+                    for k, shp in shapes.items():
+                        full[k] = torch.zeros(shp, dtype=self.dtype, device=device)
+                    torch.cuda.synchronize(device)
+                    metas = [{k: t.untyped_storage()._share_cuda_() for k, t in full.items()}]
+                except Exception as e:
+                    metas = [("error", "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:100] if str(e) else ""))]
             dist.broadcast_object_list(metas, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            if isinstance(metas[0], tuple) and metas[0][0] == "error":
+                raise RuntimeError("rank 0 could not export its buffers: " + metas[0][1])
+            mapped, why = 1, ""
             if self.rank != 0:
-                for k, shp in shapes.items():
-                    m = list(metas[0][k])
-                    m[0] = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-                    st = torch.UntypedStorage._new_shared_cuda(*m)
-                    n = 1
-                    for d in shp:
-                        n *= d
-                    full[k] = torch.empty(0, dtype=self.dtype, device=device).set_(st, 0, (n,)).view(shp)
+                try:
+                    for k, shp in shapes.items():
+                        m = list(metas[0][k])
+                        # opened on THIS rank's device (lazy peer access from it to rank 0's memory), not on the exporting one
+                        m[0] = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+                        st = torch.UntypedStorage._new_shared_cuda(*m)
+                        n = 1
+                        for d in shp:
+                            n *= d
+                        full[k] = torch.empty(0, dtype=self.dtype, device=device).set_(st, 0, (n,)).view(shp)
+                except Exception as e:                       # every rank must take the same path: the verdict is agreed on below
+                    mapped, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:100] if str(e) else "")
+            flags = [None] * self.ws
+            dist.all_gather_object(flags, (mapped, why), group=self.group)
+            if not all(f[0] for f in flags):
+                raise RuntimeError("mapping failed on rank(s) %s" % [(r, f[1]) for r, f in enumerate(flags) if not f[0]])
+            dist.barrier(group=self.group)
+            # probe: every rank writes its number into the first words of its region through the mapping; rank 0 must read them back
+            if self.rank != 0:
+                full["res"][self.rank, 0, 0, :8].fill_(float(self.rank))
+                torch.cuda.synchronize(device)
+            dist.barrier(group=self.group)
+            ok = torch.ones(1, dtype=torch.int32, device=device)
+            if self.rank == 0:
+                torch.cuda.synchronize(device)
+                for r in range(1, self.ws):
+                    if not bool((full["res"][r, 0, 0, :8] == float(r)).all()):
+                        ok.zero_()
+            if dist.get_backend(self.group) == "nccl":
+                dist.broadcast(ok, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            else:
+                okc = ok.cpu(); dist.broadcast(okc, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group); ok = okc
+            if int(ok.item()) != 1:
+                raise RuntimeError("a rank's write through the mapping did not arrive in rank 0's buffer")
+            if self.rank != 0:
+                full["res"][self.rank, 0, 0, :8].zero_()
+                torch.cuda.synchronize(device)
             dist.barrier(group=self.group)
         self.full_res = full["res"]
         self.full_trj = full.get("trj") if self.gather_traj else None
