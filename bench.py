@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--f32-pure", action="store_true", help="--precision f32 with MpcParams.f32_finish = 0: the pure fp32 solver of round 2 "
                     "(tol_f32, looser tolerances) instead of fp32 iterations finished in fp64")
     ap.add_argument("--f32-phase-refill", action="store_true", help="MpcParams.f32_phase_refill = 1 (mixed precision on heavy-tailed workloads)")
+    ap.add_argument("--fp64-only", action="store_true", help="MpcParams.f64_f32_start = 0: every iteration in fp64 at every horizon (the shipped default, "
+                    "MPC_F32_START_AUTO, starts horizons of 15 steps and more on the fp32 record)")
     ap.add_argument("--f64-f32-start", action="store_true", help="fp64 handle with MpcParams.f64_f32_start = 1: the early iterations on the fp32 "
                     "record, every instance finished by the fp64 solver (experimental)")
     ap.add_argument("--switch-mu", type=float, default=0.0, help="MpcParams.mixed_switch_mu (default 2e-5)")
@@ -92,6 +94,8 @@ def parse_args(argv=None):
                     "passes leave their launch and are finished by the handle's tail slices while later batches run; every timed batch is "
                     "final (stragglers included) inside the clock.  0 = off, -1 = MPC_TAIL_AUTO (the handle chooses; the default)")
     ap.add_argument("--tail-ring", type=int, default=128, help="batches whose tails may be outstanding per handle")
+    ap.add_argument("--outstanding", type=int, default=0, help="buffer sets = batches that may be outstanding (launched, or waiting for their stragglers); "
+                    "0 = min(256, batches in flight x tail ring)")
     ap.add_argument("--leg-tail-cut", type=int, default=None, help="override the tail cut of a leg that defers (measurement aid)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (the unfiltered population of the "
                     "headline workload and the other BASELINE.json configs)")
@@ -268,6 +272,11 @@ def cpu_twin_leg(args, pkg, params, batch, w_np, budget):
     return {"value": sum(done) / wall, "unit": "solves/s", "cores": cores, "kind": "port", "one_core": one_core,
             "sample": "CPU twin, not IPOPT: %d instances of the same batch, tests/host_twin (the device solver's header built for the CPU), "
                       "%d processes" % (sum(done), cores)}
+
+
+def f32_start_on(params):
+    """MpcParams.f64_f32_start as the library reads it: 1 = on, 2 (MPC_F32_START_AUTO) = on for horizons of 15 steps and more."""
+    return params.f64_f32_start == 1 or (params.f64_f32_start == 2 and params.N >= 15)
 
 
 class _NullCtx:
@@ -489,15 +498,15 @@ LEGS = {
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
                   dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight")),
-    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 (every iteration in fp64: the "
-                        "shipped default), SURVEY 8d's population, deferred tails, four batches in flight",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=150)),
+    "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 handle as shipped (MPC_F32_START_AUTO: "
+                        "horizons of 15 steps and more run their early iterations on the fp32 record, every instance finished by the fp64 solver), SURVEY 8d's "
+                        "population, deferred tails, four batches in flight, windows of 400 batches",
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=400)),
     "configs_3_share_filtered": ("the same share drawn with the generator's rejection sampling",
-                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=-1, steps=150)),
-    "configs_3_share_f32_start": ("the same share (SURVEY 8d's population) with MpcParams.f64_f32_start = MPC_F32_START_AUTO: horizons of 15 steps and more run their early "
-                                  "iterations on the fp32 record (the long-horizon workspace, 640 KB per wave, does not fit the Infinity Cache); eight batches in flight",
-                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=8, population="survey", tail_cut=-1, steps=150,
-                                       f32_start=True)),
+                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=-1, steps=400)),
+    "configs_3_share_fp64_only": ("the same share (SURVEY 8d's population) with MpcParams.f64_f32_start = 0: every iteration in fp64 (bitwise the host twin's solve)",
+                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=400,
+                                       f32_start=False)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states (SURVEY 8d's population), fp32 mixed precision as shipped (fp32 "
                         "iterations down to the barrier parameter 2e-5, every instance finished in fp64), per-instance weight sweep (epsi / v incl. 0 / delta / a)",
                         dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300, f32_refill=True)),
@@ -512,10 +521,11 @@ LEGS = {
 
 
 def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, config, over, B, kind, f32, sweep, want_traj, nfl, population="filtered",
-            velocity_weights=(0.0, 1.0, 100.0), note=None, tail_cut=0, steps=None, f32_pure=False, f32_start=False, f32_refill=False, hw_queues=8):
+            velocity_weights=(0.0, 1.0, 100.0), note=None, tail_cut=0, steps=None, f32_pure=False, f32_start=None, f32_refill=False, hw_queues=8, outstanding=0):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
     params = pkg.params_from_json(os.path.join(golden, config), **over)
-    params.f64_f32_start = (2 if params.N >= 15 else 1) if f32_start else 0
+    if f32_start is not None:                         # None: as shipped (MPC_F32_START_AUTO: on for horizons of 15 steps and more)
+        params.f64_f32_start = 1 if f32_start else 0
     params.f32_phase_refill = 1 if f32_refill else 0
     if f32:
         params.precision = pkg.PRECISION_F32
@@ -536,7 +546,7 @@ def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, c
     if args.leg_tail_cut is not None and tail_cut:
         tail_cut = args.leg_tail_cut
     pipe = Pipeline(pkg, torch, params, B, tens, t(w, tdt) if w is not None else None, want_traj, nfl, dev, local_rank, None, args,
-                    tail_cut=tail_cut, tail_ring=args.tail_ring, outstanding=min(256, nfl * args.tail_ring))
+                    tail_cut=tail_cut, tail_ring=args.tail_ring, outstanding=outstanding or args.outstanding or min(256, nfl * args.tail_ring))
     # (every handle's first calls allocate lazily -- second workspace, tail queues: they happen while the pipeline is primed)
     tr = timed_run(pipe, steps, 4 * pipe.nfl, sync_all)
     r, _, _, _ = summarize(pkg, np, pipe, B, steps, tr["steady_s"])
@@ -665,7 +675,11 @@ def main():
     if f32:
         params.precision = pkg.PRECISION_F32
         params.f32_finish = 0 if args.f32_pure else 1
-    params.f64_f32_start = 1 if args.f64_f32_start else 0
+    # (as shipped: MPC_F32_START_AUTO = the fp32 start for horizons of 15 steps and more)
+    if args.f64_f32_start:
+        params.f64_f32_start = 1
+    elif args.fp64_only:
+        params.f64_f32_start = 0
     params.f32_phase_refill = 1 if args.f32_phase_refill else 0
     if args.switch_mu > 0:
         params.mixed_switch_mu = args.switch_mu
@@ -699,7 +713,7 @@ def main():
     # while the average wave is done after ~70 % of that time; a second handle on a second stream lets the next batch's
     # waves take the SIMDs as they become free (measured: 2.2 -> 1.3 ms per batch).
     pipe = Pipeline(pkg, torch, params, B, tensors, d_w, want_traj, args.inflight, dev, local_rank, dist, args, stub=stub,
-                    tail_cut=args.tail_cut, tail_ring=args.tail_ring, outstanding=min(256, args.inflight * args.tail_ring))
+                    tail_cut=args.tail_cut, tail_ring=args.tail_ring, outstanding=args.outstanding or min(256, args.inflight * args.tail_ring))
     nfl, pg = pipe.nfl, pipe.pg
 
     def sync_all():
@@ -790,7 +804,7 @@ def main():
                    "branch_mode": "frozen", "tol": params.tol_f32 if f32 else params.tol, "max_iter": params.max_iter,
                    "termination_polish": bool(params.polish), "bound_relax_factor": params.bound_relax_factor, "pass_cuts": cuts,
                    "mixed_precision": ("fp32 iterations to mu = %g, every instance finished in fp64" % params.mixed_switch_mu) if ((f32 and params.f32_finish) or
-                                                                                                                                (not f32 and params.f64_f32_start)) else "no",
+                                                                                                                                (not f32 and f32_start_on(params))) else "no",
                    "deferred_tails": summary.get("tails", "off"), "tail_cut": pipe.tail,
                    "lane_compact": int(os.environ.get("MPC_LANE_COMPACT", params.lane_compact if params.lane_compact >= 0 else (1 if params.N >= 15 else 2))) if B >= 8192 else 0,
                    # "survey": SURVEY.md 8d's population (only a compensated speed above Config::maxSpeed is redrawn); the leg "filtered"
@@ -825,7 +839,7 @@ def main():
         except Exception:
             continue
         for e in pj.get("entries", [pj]):
-            mixed_now = (f32 and bool(params.f32_finish)) or (not f32 and bool(params.f64_f32_start))
+            mixed_now = (f32 and bool(params.f32_finish)) or (not f32 and f32_start_on(params))
             if (e.get("batch") == B and e.get("config") == args.config and e.get("N", 10) == params.N and e.get("dtype", "f64") == dtype
                     and bool(e.get("weights_sweep", False)) == bool(args.weights_sweep) and bool(e.get("traj", True)) == want_traj
                     and (e.get("mixed_precision", "no") != "no") == mixed_now):

@@ -103,7 +103,7 @@ extern "C" int mpc_params_default(MpcParams *p) {
   p->honor_original_bounds = 1;
   p->bound_relax_factor = 1e-8;            /* IPOPT default */
   p->tail_cut = 0; p->tail_ring = 128; p->tail_capacity = 0;
-  p->f32_finish = 1; p->f64_f32_start = MPC_F32_START_OFF; p->mixed_switch_mu = 2e-5;
+  p->f32_finish = 1; p->f64_f32_start = MPC_F32_START_AUTO; p->mixed_switch_mu = 2e-5;
   p->lane_compact = MPC_LANE_COMPACT_AUTO; p->f32_phase_refill = 0;
   /* IPOPT 3.12 defaults of the termination tests the reference's option string leaves alone (MPC.cpp:160-179) */
   p->acceptable_iter = 15; p->dual_inf_tol = 1.0; p->constr_viol_tol = 1e-4; p->compl_inf_tol = 1e-4;

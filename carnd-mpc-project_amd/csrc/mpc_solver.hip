@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -601,7 +602,8 @@ struct MpcSliceArgs {
   int32_t *remaining;              /* [ring] */
   long long *final_id;             /* [ring], pinned host memory: the id of the batch that has become final in the slot */
   int32_t *res;                    /* pinned host memory: what the pump reads when the slice has completed -- [0] survivors left,
-                                    * [j] entries of source j */
+                                    * [j] entries of source j; [25..27]: entries finished / moved on untouched / parked again */
+  int32_t *tally;                  /* [4]: those three, and the most passes a wave of the slice made */
 };
 
 template <bool STAGING, class R, int OCC, class RIO = R>
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
         if (it_arr) it_arr[i] = S.iters + it_total;
         const int old = atomicSub(A.remaining + slot, 1);
         if (old == 1) __hip_atomic_store(A.final_id + slot, (long long)pm[2 * lp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicAdd(A.tally, 1);
       }
       fin = false;
     }
@@ -677,6 +680,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
           if (dpos >= A.dst.cap) { dpos = -1; keep = true; }
         }
         if (dpos >= 0) {
+          atomicAdd(A.tally + 1, 1);
           double *dk = A.dst.park + dpos;
           const int64_t dl = A.dst.cap;
           rows_copy(dk, dl, pk, lp, 0, kTailRows);
@@ -731,6 +735,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
         const int dpos = atomicAdd(A.dst.count, 1);
         if (dpos >= A.dst.cap) keep = true;
         else {
+          atomicAdd(A.tally + 2, 1);
           double *dk = A.dst.park + dpos;
           const int64_t dl = A.dst.cap;
           S.park([dk, dl](int q) -> double & { return dk[q * dl]; }, attempt, it_total);
@@ -749,8 +754,14 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
    * its own work counters serve the slice that takes this ring position again.  (Every wave's additions to the counters have
    * returned before it arrives here: their results decided what it did.) */
   if (threadIdx.x == 0) {
+    atomicMax(A.tally + 3, wp);
     const int arrived = atomicAdd(A.done, 1);
     if (arrived == (int)gridDim.x - 1) {
+      for (int q = 0; q < 4; q++) {
+        const int v = __hip_atomic_load(A.tally + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.res + (q < 3 ? 25 + q : 31), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.tally + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const int dc = __hip_atomic_load(A.dst.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(A.res, dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       for (int j = 1; j < A.n_src; j++) {
@@ -1034,7 +1045,7 @@ struct MpcHandle {
   };
   static constexpr int kBatchRecs = 1024;
   struct SliceRes { int32_t count[32]; };     /* [0]: survivors the slice left; [j]: entries of its source j */
-  static_assert(kSliceMaxSrc <= 32, "SliceRes");
+  static_assert(kSliceMaxSrc <= 25, "SliceRes: [25..31] carry the tallies and the damaged-entry report");
   bool tail_ready = false;
   bool tail_double = true;     /* the solver of the tail slices: fp64, or fp32 on a pure MPC_PRECISION_F32 handle */
   int tail_ring = 0, tail_waves = 256, tail_priority = 0, slice_passes = 16;
@@ -1044,7 +1055,7 @@ struct MpcHandle {
   int64_t tail_cap = 0, surv_cap = 0, tail_min_batch = 4096;
   hipStream_t tail_stream = nullptr;
   MpcTailQ fq_dev[kFreshRing] = {}, surv_dev[2] = {};   /* device storage of the fresh queues and the two survivor lists */
-  int32_t *d_tcount = nullptr;   /* [kFreshRing + 2 + 2 kSliceRing]: counts of the fresh queues, of the survivor lists, slice work and exit counters */
+  int32_t *d_tcount = nullptr;   /* [kFreshRing + 2 + 6 kSliceRing]: counts of the fresh queues, of the survivor lists, slice work and exit counters, slice tallies */
   int32_t *d_remaining = nullptr;
   long long *h_final = nullptr;  /* pinned: [tail_ring] the id of the batch that has become final in each slot (written by the slices) */
   SliceRes *h_res = nullptr;     /* pinned: [kSliceRing], written by each slice's last wave */
@@ -1054,6 +1065,9 @@ struct MpcHandle {
   BatchRec *brec = nullptr;
   hipEvent_t slice_ev[kSliceRing] = {};
   struct Absorbed { int fq; int slot; int64_t batch; };
+  /* measurement aid: MPC_TAIL_TRACE=<file> appends one line per retired slice (see tail_retire) */
+  int64_t slice_t0[kSliceRing] = {}, slice_est[kSliceRing] = {}, slice_surv_in[kSliceRing] = {};
+  int slice_waves[kSliceRing] = {};
   int slice_nabs[kSliceRing] = {};            /* fresh queues slice k % kSliceRing absorbed, and which (queue, its batch and slot) */
   Absorbed slice_abs[kSliceRing][kFreshRing] = {};
   int64_t n_slice = 0, n_slice_done = 0;      /* slices launched / retired */
@@ -1235,7 +1249,10 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   if ((e = hipMalloc((void **)&h->d_status, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_iters, sizeof(int32_t) * h->io_stride)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMalloc((void **)&h->d_counter, kCounterRing * kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMemset(h->d_counter, 0, kCounterRing * kCounterInts * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMemset");
+  /* (on the handle's own stream and waited for: a plain hipMemset of device memory is ordered on the null stream only, which the
+   * non-blocking streams the launches run on do not wait for) */
+  if ((e = hipMemsetAsync(h->d_counter, 0, kCounterRing * kCounterInts * sizeof(int32_t), h->stream)) != hipSuccess) return fail(e, "hipMemset");
+  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
   if ((e = hipMalloc((void **)&h->d_stats, kStatWords * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   set_cuts(h, p);
@@ -1420,20 +1437,25 @@ static int tail_prepare(MpcHandle *h) {
   if (const char *e = getenv("MPC_TAIL_AUTO_CUT")) { h->auto_cut = atoi(e); if (h->auto_cut < 4) h->auto_cut = 4; }
   if (const char *e = getenv("MPC_TAIL_AUTO_LO")) h->auto_lo = atoll(e);
   if (const char *e = getenv("MPC_TAIL_AUTO_HI")) h->auto_hi = atoll(e);
-  /* The tail stream's priority: normal (MPC_TAIL_PRIORITY=low|normal|high to measure the others).  The slices are short and
-   * follow each other without a gap, so they need no head start; measured on the survey population, bulk launches on
-   * high-priority streams: tail stream high 44.7, normal or low 46.3 M solves/s. */
+  /* The tail stream's priority: high (MPC_TAIL_PRIORITY=low|normal|high to measure the others).  A slice is a few dozen waves that
+   * must find free SIMDs on a device the launches keep full: at normal priority a slice at N = 25 waited 6-12 ms for its 1.8 ms of
+   * work (p90 of the retirement interval 15-30 ms), the stragglers' backlog grew until every buffer set was taken, and the long
+   * windows read 5.4 M solves/s where the launches alone give 7.6 M; at high priority 7.1-8.8 M.  At N = 10 it makes no
+   * difference (46.8 M either way; an earlier build of the slices lost 3 % with it). */
   int lo = 0, hi = 0;
   MPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      /* lo = least, hi = greatest priority (numerically smaller) */
-  int prio = 0;
+  int prio = hi;
   if (const char *e = getenv("MPC_TAIL_PRIORITY")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "normal") ? 0 : hi);
   h->tail_priority = prio;
   if (!h->tail_stream) MPC_HIP_CHECK(hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, prio));
-  const int n_counts = kFreshRing + 2 + 2 * kSliceRing;
+  /* the counters start from zero BEFORE the first launch that adds to them is issued: cleared on the tail stream and waited for
+   * below (a plain hipMemset runs on the null stream, which neither the caller's stream nor the tail stream waits for -- on a
+   * device that other handles keep full its fill kernel can start after the launch that follows this call) */
+  const int n_counts = kFreshRing + 2 + 6 * kSliceRing;
   if (!h->d_tcount) MPC_HIP_CHECK(hipMalloc((void **)&h->d_tcount, sizeof(int32_t) * n_counts));
-  MPC_HIP_CHECK(hipMemset(h->d_tcount, 0, sizeof(int32_t) * n_counts));
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_tcount, 0, sizeof(int32_t) * n_counts, h->tail_stream));
   if (!h->d_remaining) MPC_HIP_CHECK(hipMalloc((void **)&h->d_remaining, sizeof(int32_t) * kTailMaxRing));
-  MPC_HIP_CHECK(hipMemset(h->d_remaining, 0, sizeof(int32_t) * kTailMaxRing));
+  MPC_HIP_CHECK(hipMemsetAsync(h->d_remaining, 0, sizeof(int32_t) * kTailMaxRing, h->tail_stream));
   if (!h->h_final) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_final, sizeof(long long) * kTailMaxRing, hipHostMallocDefault));
   if (!h->h_res) MPC_HIP_CHECK(hipHostMalloc((void **)&h->h_res, sizeof(MpcHandle::SliceRes) * kSliceRing, hipHostMallocDefault));
   memset(h->h_final, 0, sizeof(long long) * kTailMaxRing);
@@ -1450,6 +1472,7 @@ static int tail_prepare(MpcHandle *h) {
   if (!h->tail_ws) MPC_HIP_CHECK(hipMalloc((void **)&h->tail_ws, (size_t)tail_stride * (size_t)h->tail_waves * real_bytes));
   for (int q = 0; q < kSliceRing; q++)
     if (!h->slice_ev[q]) MPC_HIP_CHECK(hipEventCreateWithFlags(&h->slice_ev[q], hipEventDisableTiming));
+  MPC_HIP_CHECK(hipStreamSynchronize(h->tail_stream));
   h->tail_ready = true;
   return MPC_OK;
 }
@@ -1464,6 +1487,14 @@ static int batch_rec(MpcHandle *h, int64_t id, MpcHandle::BatchRec **out) {
 }
 
 static int tail_retire(MpcHandle *h, bool block, int *n_retired);
+
+static FILE *g_tail_trace = nullptr;
+static std::once_flag g_tail_trace_once;
+static int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static FILE *tail_trace() {
+  std::call_once(g_tail_trace_once, [] { if (const char *e = getenv("MPC_TAIL_TRACE")) g_tail_trace = fopen(e, "a"); });
+  return g_tail_trace;
+}
 
 /* Starts tail slice number h->n_slice.  It absorbs every filled fresh queue whose launch has ended (`force`: every filled one --
  * the slice then waits for those launches on the device). */
@@ -1506,6 +1537,7 @@ static int tail_launch_slice(MpcHandle *h, bool force) {
   h->h_res[kr].count[28] = 0;
   A.take = h->d_tcount + kFreshRing + 2 + kr; A.done = h->d_tcount + kFreshRing + 2 + kSliceRing + kr;
   A.remaining = h->d_remaining; A.final_id = h->h_final; A.res = h->h_res[kr].count;
+  A.tally = h->d_tcount + kFreshRing + 2 + 2 * kSliceRing + 4 * kr;
   int64_t waves = (est + 63) / 64 + 1;
   if (waves > h->tail_waves) waves = h->tail_waves;
   if (waves < 1) waves = 1;
@@ -1523,6 +1555,7 @@ static int tail_launch_slice(MpcHandle *h, bool force) {
   /* (what the pump reads when the slice has completed -- the survivors it left, what each absorbed batch handed over, the final
    * flags -- the slice's last wave writes into pinned host memory itself) */
   MPC_HIP_CHECK(hipEventRecord(h->slice_ev[kr], ts));
+  if (tail_trace()) { h->slice_t0[kr] = now_us(); h->slice_est[kr] = est; h->slice_surv_in[kr] = h->surv_last; h->slice_waves[kr] = (int)waves; }
   ++h->n_slice;
   return MPC_OK;
 }
@@ -1545,6 +1578,15 @@ static int tail_retire(MpcHandle *h, bool block, int *n_retired) {
       return MPC_ERR_HIP;
     }
     h->surv_last = res.count[0] < h->surv_cap ? res.count[0] : h->surv_cap;
+    if (FILE *f = tail_trace()) {
+      int64_t fresh = 0;
+      for (int a = 0; a < h->slice_nabs[kr]; a++) fresh += res.count[1 + a];
+      /* handle, slice, issued at / seen complete at (host, microseconds), waves, fresh queues absorbed, survivors known when it was issued,
+       * fresh entries, survivors left, finished, moved on untouched, parked again, most passes of a wave, batches not final, slices in flight */
+      fprintf(f, "%p %lld %lld %lld %d %d %lld %lld %d %d %d %d %d %d %lld\n", (void *)h, (long long)h->n_slice_done, (long long)h->slice_t0[kr], (long long)now_us(),
+              h->slice_waves[kr], h->slice_nabs[kr], (long long)h->slice_surv_in[kr], (long long)fresh, res.count[0], res.count[25], res.count[26], res.count[27],
+              res.count[31], (int)h->n_not_final, (long long)(h->n_slice - h->n_slice_done));
+    }
     for (int a = 0; a < h->slice_nabs[kr]; a++) {
       const MpcHandle::Absorbed &Ab = h->slice_abs[kr][a];
       MpcHandle::FreshQ &F = h->fq[Ab.fq];

@@ -152,9 +152,13 @@ typedef struct MpcParams {
    * so is one the fp64 phase cannot finish from the fp32 iterate: on hard instances fp32 iterates lead into other
    * local minima than fp64 ones.  With that rule the CPU build gives the single-phase solve's status and point (1e-7)
    * on every instance of SURVEY's unfiltered populations (65 536 at N = 10, 32 768 at N = 25).
-   * Default 0 (off), because it is not a win everywhere: 1.12x on the filtered headline workload (four batches in
-   * flight), 1.5x at N = 25 on the same generator, but slower than the single-phase solve on SURVEY's unfiltered
-   * populations, whose restarted instances are long chains. */
+   * Default MPC_F32_START_AUTO: long horizons start on the fp32 record.  Measured in round 4 with the tail slices on the
+   * tail stream's high priority (windows of 600 batches): N = 25, SURVEY's population 9.8-10.0 M against 7.1-8.8 M solves/s,
+   * the filtered generator 11.0-11.9 against 7.6 M; 0 status differences and at most 4.1e-8 rad on the first steering
+   * angle over the 32 768 instances of SURVEY's N = 25 population (profiles/r04_f32start_vs_plain.jsonl).  Not for short
+   * horizons: at N = 10 the workspace of a full device lives in the Infinity Cache and the two launches of the mixed
+   * solve cost more than the bytes save (44 against 52 M on the filtered headline): f64_f32_start = 1 stays a choice.
+   * MPC_F32_START_OFF gives the single-phase fp64 solve at every horizon (bitwise the host twin's). */
   int32_t f32_finish;
   int32_t f64_f32_start;
   double mixed_switch_mu;          /* default 2e-5 */

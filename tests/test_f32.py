@@ -95,14 +95,13 @@ def test_f32_finish_twin_matches_fp64_twin_at_scale(pkg, host_twin, golden_dir, 
 
 
 def test_f64_f32_start_auto_for_long_horizons_and_the_single_phase_verdict(pkg, host_twin, golden_dir, waypoints):
-    """MpcParams.f64_f32_start = MPC_F32_START_AUTO (opt-in): fp64 handles with N >= 15 run their early iterations on the fp32
+    """MpcParams.f64_f32_start = MPC_F32_START_AUTO (the default): fp64 handles with N >= 15 run their early iterations on the fp32
     record.  The whole N = 25 batch of the full-size soak (8 192 instances) through the host replay of the two phases: same status
     as the single-phase solve on every instance, outputs within the fp64 tolerances -- including the instances the fp64 phase
     cannot finish from where fp32 left them (a failed line search on the device before this rule existed): those are solved again
     from the start point exactly as the single-phase solve does it, and so return its status and its point."""
     params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json"), N=25, dt=0.05)
-    assert params.f64_f32_start == 0                      # off by default (forks on the hard instances of SURVEY's unfiltered population)
-    params.f64_f32_start = 2                              # MPC_F32_START_AUTO: on from N = 15
+    assert params.f64_f32_start == 2                      # MPC_F32_START_AUTO, as shipped: on from N = 15
     B = 8192
     b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=103)
     r = twin_solve_mixed_f64(host_twin, params, b)

@@ -107,5 +107,78 @@ except Exception as e:
 PY
   done
   ;;
+h)   # the fp32 start on the filtered and on SURVEY's populations, with the tail slices
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  for pop in filtered survey; do
+    run n10_${pop}_plain --steps 200 --population $pop
+    run n10_${pop}_f32start --steps 200 --population $pop --f64-f32-start
+    run n25_${pop}_plain --steps 100 --population $pop $N25
+    run n25_${pop}_f32start --steps 100 --population $pop $N25 --f64-f32-start
+  done
+  ;;
+i)   # N = 25 on SURVEY's population, long windows: plain against the fp32 start
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768"
+  run n25_survey_plain_i4 --steps 500 $N25 --inflight 4
+  run n25_survey_f32start_i4 --steps 500 $N25 --inflight 4 --f64-f32-start
+  run n25_survey_f32start_i8 --steps 500 $N25 --inflight 8 --f64-f32-start
+  run n25_filtered_plain_i4 --steps 500 $N25 --inflight 4 --population filtered
+  run n25_filtered_f32start_i4 --steps 500 $N25 --inflight 4 --population filtered --f64-f32-start
+  run n25_filtered_f32start_i8 --steps 500 $N25 --inflight 8 --population filtered --f64-f32-start
+  ;;
+j)   # N = 25 on SURVEY's population, long windows: what keeps the slices from keeping up
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  MPC_TAIL_PRIORITY=high run n25_prio_high --steps 400 $N25
+  MPC_SLICE_PASSES=32 run n25_sp32 --steps 400 $N25
+  MPC_TAIL_PRIORITY=high MPC_SLICE_PASSES=32 run n25_prio_high_sp32 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 run n25_cut32 --steps 400 $N25
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=32 run n25_prio_high_cut32 --steps 400 $N25
+  MPC_TAIL_PRIORITY=high MPC_TAIL_WAVES=512 run n25_prio_high_w512 --steps 400 $N25
+  MPC_TAIL_PRIORITY=high run n25_prio_high_i2 --steps 400 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 2
+  MPC_TAIL_PRIORITY=high run n10_prio_high --steps 400
+  run n10_plain --steps 400
+  ;;
+k)   # N = 25 on SURVEY's population, tail stream high priority: waves per slice, passes per slice, the cut
+  export GPU_MAX_HW_QUEUES=8 MPC_TAIL_PRIORITY=high
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  MPC_TAIL_AUTO_CUT=32 MPC_SLICE_FRESH_DIV=1 run n25_c32_fd1 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 MPC_SLICE_FRESH_DIV=2 run n25_c32_fd2 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 MPC_SLICE_PASSES=8 run n25_c32_sp8 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 MPC_SLICE_PASSES=24 run n25_c32_sp24 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=40 run n25_c40 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=48 run n25_c48 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 MPC_TAIL_FEW=0 run n25_c32_few0 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 MPC_TAIL_WAVES=512 run n25_c32_w512 --steps 400 $N25
+  MPC_TAIL_AUTO_CUT=32 run n25_c32_f32start --steps 400 $N25 --f64-f32-start
+  ;;
+l)   # what the slices do at N = 25 and N = 10 (MPC_TAIL_TRACE)
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  rm -f $OUT/r04l_trace_*.txt
+  MPC_TAIL_TRACE=$OUT/r04l_trace_n25.txt run n25_trace --steps 400 $N25
+  python tools/slice_trace.py $OUT/r04l_trace_n25.txt 100 | tee -a $P
+  MPC_TAIL_PRIORITY=high MPC_TAIL_TRACE=$OUT/r04l_trace_n25_high.txt run n25_trace_high --steps 400 $N25
+  python tools/slice_trace.py $OUT/r04l_trace_n25_high.txt 100 | tee -a $P
+  MPC_TAIL_TRACE=$OUT/r04l_trace_n10.txt run n10_trace --steps 400
+  python tools/slice_trace.py $OUT/r04l_trace_n10.txt 100 | tee -a $P
+  ;;
+m)   # N = 25 on SURVEY's population: buffer sets (batches outstanding), tail stream priority, the cut
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4"
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=32 run n25_high_c32_o512 --steps 600 $N25 --outstanding 512
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=24 run n25_high_c24_o512 --steps 600 $N25 --outstanding 512
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=32 run n25_high_c32_o256 --steps 600 $N25
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=24 run n25_high_c24_o256 --steps 600 $N25
+  MPC_TAIL_PRIORITY=normal MPC_TAIL_AUTO_CUT=32 run n25_norm_c32_o512 --steps 600 $N25 --outstanding 512
+  MPC_TAIL_PRIORITY=high MPC_TAIL_AUTO_CUT=32 run n25_high_c32_o512_f32start --steps 600 $N25 --outstanding 512 --f64-f32-start
+  MPC_TAIL_PRIORITY=high run n10_high_o512 --steps 600 --outstanding 512
+  ;;
+n)   # the whole GPU suite with MPC_F32_START_AUTO as the default and the tail stream on high priority; the N = 25 legs
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $OUT/r04n_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -6 $OUT/r04n_pytest.log
+  LEGS_G="configs_3_share configs_3_share_filtered configs_3_share_fp64_only" bash tools/r04_session.sh g
+  ;;
 esac
 echo done | tee -a $P
