@@ -180,5 +180,15 @@ n)   # the whole GPU suite with MPC_F32_START_AUTO as the default and the tail s
   timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $OUT/r04n_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -6 $OUT/r04n_pytest.log
   LEGS_G="configs_3_share configs_3_share_filtered configs_3_share_fp64_only" bash tools/r04_session.sh g
   ;;
+p)   # the round's evidence on the final build: full-scale soak, kernel trace and PMC passes of the driver's command
+  export GPU_MAX_HW_QUEUES=8
+  rm -f $OUT/soak*.json
+  ( time MPC_SOAK=1 MPC_SOAK_WORKERS=60 timeout -k 10 900 python -m pytest tests/test_soak.py -m gpu -q -x > $OUT/r04p_soak.log 2>&1 ) 2>&1 | tail -3 | tee -a $P; tail -3 $OUT/r04p_soak.log | tee -a $P
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r04p_prof -o trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04p_prof_bench.json > /dev/null 2> $OUT/r04p_prof.err; echo "rocprof exit=$?" | tee -a $P
+  for c in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/r04p_pmc_$c -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04p_pmc_$c.json > /dev/null 2> $OUT/r04p_pmc_$c.err; echo "pmc $c exit=$?" | tee -a $P; done
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/r04p_pmc_sq -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04p_pmc_sq.json > /dev/null 2> $OUT/r04p_pmc_sq.err; echo "pmc sq exit=$?" | tee -a $P
+  cd $R
+  ;;
 esac
 echo done | tee -a $P
