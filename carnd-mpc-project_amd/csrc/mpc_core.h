@@ -44,6 +44,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mpc_amd.h"
 
@@ -106,7 +107,11 @@ template <class R> struct Fields : Layout<R> {
   static_assert(L::F_ZL % L::G == 0 && L::F_ZU == L::F_ZL + 4 && L::F_U == L::F_S + 6, "blocks the forward sweep fetches");
 };
 
-MPC_HD int64_t workspace_fields_per_instance(int N, bool f32) { return (int64_t)(N - 1) * (f32 ? (int)Fields<float>::STAGE_SZ : (int)Fields<double>::STAGE_SZ); }
+/* (N - 1 stages; with MpcParams.initial_state_rows one more record for the multipliers and bound duals of the initial state's
+ * own rows: Solver::s0_lam) */
+MPC_HD int64_t workspace_fields_per_instance(int N, bool f32, bool s0_rows = false) {
+  return (int64_t)(N - 1 + (s0_rows ? 1 : 0)) * (f32 ? (int)Fields<float>::STAGE_SZ : (int)Fields<double>::STAGE_SZ);
+}
 
 /* Plain storage for the test-only host build: one instance, fields contiguous. */
 template <class R>
@@ -628,14 +633,31 @@ struct Solver {
    * unbounded components that never does anything; psi_0 (a closed loop whose heading has reached its bound,
    * test.cpp:79-111) and v_0 (a car at Config::maxSpeed) take a few iterations, during which stage 0 is linearised at
    * (psi_0^k, v_0^k), its residual counts in theta and its slacks limit the step.  These two scalars carry exactly that;
-   * the multipliers of the six pinning rows and the bound duals of psi_0, v_0 (which decouple: the rows hold a free
-   * multiplier with unit coefficient) are not carried.  -DMPC_S0_VARIABLE=0 builds the solver with the initial state as
-   * plain data (A/B measurements only). */
+   * the multipliers of the six pinning rows (lam0) and the bound duals of psi_0, v_0 (z0) decouple from the step -- the rows
+   * hold a free multiplier with unit coefficient -- but not from IPOPT's error measure: the stationarity rows of the six
+   * initial-state variables count in the dual infeasibility (after a step the fraction-to-the-boundary rule has cut they hold
+   * (1 - alpha) of their old residual plus the curvature of stage 0 along the step), lam0 counts in its scaling, z0 in the
+   * complementarity and in the dual step length.  They are carried for that: costate_trial() treats them as the record of a
+   * stage "-1".  -DMPC_S0_VARIABLE=0 builds the solver with the initial state as plain data (A/B
+   * measurements only). */
 #ifndef MPC_S0_VARIABLE
 #define MPC_S0_VARIABLE 1
 #endif
 #if MPC_S0_VARIABLE
   R p0, v0k;
+  R wc0, we0, vref0, wneg0;   /* the i = 0 terms of the objective (MPC.cpp:71-92), whose variables are the initial state's */
+  bool s0_rows = false;       /* MpcParams.initial_state_rows: lam0 / z0 carried and counted in the error measure */
+  /* lam0 and z0 live in the workspace, in the iterate slots of a record of their own behind the last stage's (index M: lam0 in
+   * the multipliers' fields, the duals of psi_0 / v_0 where a stage keeps those of psi_{k+1} / v_{k+1}): current and trial
+   * values swap with `cur` like every other record, and the solver's registers are left to the sweeps */
+  MPC_HD R s0_lam(int I, int i) const { return ws.it(M, I, F_LAM + i); }
+  MPC_HD R s0_z(int I, int b, int upper) const { return ws.it(M, I, (upper ? F_ZU : F_ZL) + b); }
+  MPC_HD void s0_reset(int I) {
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) ws.it(M, I, F_LAM + i) = R(0.0);
+    MPC_UNROLL
+    for (int b = 0; b < 2; b++) { ws.it(M, I, F_ZL + b) = R(1.0); ws.it(M, I, F_ZU + b) = R(1.0); }      /* bound_mult_init_val */
+  }
 #endif
   /* interior-point state */
   int cur;     /* slot of the current iterate */
@@ -983,11 +1005,17 @@ struct Solver {
       dphi = mu * ((isup - islp) * d2 + (isuv - islv) * d3);
       dxinf = mpc_max(mpc_abs(d2), mpc_abs(d3));
     }
+    const R s0d2 = d2, s0d3 = d3;
 #endif
     /* staging: stage k's iterate record and gains in buffer k&1, stage k+1 requested meanwhile */
     ws.stage_drain();
     ws.stage_fetch_itf(0, 0, I);
     ws.stage_fetch_g(0, 0, J);
+#if MPC_S0_VARIABLE
+    /* (asked for here, used behind the loop: the loads travel with the first record's) */
+    R z0lp = R(1.0), z0up = R(1.0), z0lv = R(1.0), z0uv = R(1.0);
+    if (s0_rows) { z0lp = s0_z(I, 0, 0); z0up = s0_z(I, 0, 1); z0lv = s0_z(I, 1, 0); z0uv = s0_z(I, 1, 1); }
+#endif
     MPC_STAGE_LOOP
     for (int k = 0; k < M; ++k) {
       const int bf = k & 1;
@@ -1047,8 +1075,22 @@ struct Solver {
       MPC_UNROLL
       for (int i = 0; i < 6; i++) sk[i] = sn[i];
     }
-    /* fraction to the boundary, W&B eq. (15): alpha = min(1, tau / max ratio) */
-    amax = (rmax > tau) ? tau / rmax : R(1.0);
+    #if MPC_S0_VARIABLE
+        if (s0_rows && !lsm) {
+          /* the bound duals of psi_0, v_0 take part in the fraction-to-the-boundary rule of the duals */
+          const R xs0[2] = {p0, v0k}, lo0[2] = {yl, vl}, hi0[2] = {yu, vu}, dx0[2] = {s0d2, s0d3};
+          const R zl0[2] = {z0lp, z0lv}, zu0[2] = {z0up, z0uv};
+          MPC_UNROLL
+          for (int b = 0; b < 2; b++) {
+            const R isl = frcp1(xs0[b] - lo0[b]), isu = frcp1(hi0[b] - xs0[b]);
+            const R dzl = mu * isl - zl0[b] - zl0[b] * isl * dx0[b];
+            const R dzu = mu * isu - zu0[b] + zu0[b] * isu * dx0[b];
+            rzmax = mpc_max(rzmax, mpc_max(-dzl * frcp1(zl0[b]), -dzu * frcp1(zu0[b])));
+          }
+        }
+    #endif
+        /* fraction to the boundary, W&B eq. (15): alpha = min(1, tau / max ratio) */
+        amax = (rmax > tau) ? tau / rmax : R(1.0);
     az = (rzmax > tau) ? tau / rzmax : R(1.0);
   }
 
@@ -1085,176 +1127,263 @@ struct Solver {
     ws.stage_drain();
     ws.stage_fetch_it(0, M - 1, I);
     ws.stage_fetch_d(0, M - 1);
-    MPC_STAGE_LOOP
-    for (int k = M; k >= 0; --k) {
-      const int bk = (M - k) & 1;                    /* buffer of record k-1 */
-      R s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
-      R zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0;     /* trial duals of psi_k, v_k: zl_psi, zu_psi, zl_v, zu_v */
-      R n_del_o = 0, n_acc_o = 0, n_ddk = 0, lo0 = 0, lo1 = 0, lo2 = 0, lo4 = 0, lo5 = 0;
-      R n_del_t = 0, n_acc_t = 0, n_zdl = 0, n_zdu = 0, n_zal = 0, n_zau = 0;
-      if (k >= 1) {
-        if (k >= 2) {
-          ws.stage_fetch_it(bk ^ 1, k - 2, I);
-          ws.stage_fetch_d(bk ^ 1, k - 2);
-          if (k == M) ws.template stage_wait<STG_IT_OPS + STG_D_OPS>();
-          else ws.template stage_wait<STG_IT_OPS + STG_D_OPS + ST_TRIAL>();
-        } else ws.template stage_wait<0>();
-        const int r = k - 1;
-        R ds[6];
-        MPC_UNROLL
-        for (int i = 0; i < 6; i++) { s_o[i] = ws.sit(bk, r, I, F_S + i); ds[i] = ws.sx(bk, r, F_D, D_S + i); }
-        const R lo3 = ws.sit(bk, r, I, F_LAM + 3);
-        lo0 = ws.sit(bk, r, I, F_LAM + 0); lo1 = ws.sit(bk, r, I, F_LAM + 1); lo2 = ws.sit(bk, r, I, F_LAM + 2);
-        lo4 = ws.sit(bk, r, I, F_LAM + 4); lo5 = ws.sit(bk, r, I, F_LAM + 5);
-        n_del_o = ws.sit(bk, r, I, F_U + 0); n_acc_o = ws.sit(bk, r, I, F_U + 1);
-        const R ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
-        n_ddk = ddel;
-        if (r == 0) Ev.du0 = mpc_max(mpc_abs(ddel), mpc_abs(dacc));   /* the outputs' part of the step (termination polish) */
-        /* ---- costate: lam+_k ---- */
-        R dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
-        if (with_costate) {
-          R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
-          state_terms(s_o[2], s_o[3], s_o[4], s_o[5], ws.sit(bk, r, I, F_ZL + 0), ws.sit(bk, r, I, F_ZU + 0),
-                      ws.sit(bk, r, I, F_ZL + 1), ws.sit(bk, r, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
-          R n0, n1, n2, n3, n4, n5;
-          if (k == M) {
-            n0 = -(hxy * ds[0]);
-            n1 = -(hxy * ds[1]);
-            n2 = -(gp + (Hpp + dw) * ds[2]);
-            n3 = -(gv + (Hvv + dw) * ds[3]);
-            n4 = -(gc + (Hcc + dw) * ds[4]);
-            n5 = -(ge + (Hee + dw) * ds[5]);
-          } else {
-            const R v = s_o[3];
-            LinR L;
-            linearise(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
-            const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
-            const R vdt = v * dt, Apv = del_o * dtLf;
-            /* curvature of stage k */
-            const R Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
-            const R Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
-            const R L25 = L2 + L5;
-            n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * ds[0];
-            n1 = L1 - L4 - hxy * ds[1];
-            n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds[2] - Hpv * ds[3];
-            n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * ds[2] -
-                 (Hvv + dw) * ds[3] - Hev * ds[5] - Hvd * ddk;
-            n4 = -gc - (Hcc + dw) * ds[4];
-            n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * ds[5] - Hev * ds[3];
-          }
-          L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
-          dl0 = L0 - lo0; dl1 = L1 - lo1; dl2 = L2 - lo2; dl3 = L3 - lo3; dl4 = L4 - lo4; dl5 = L5 - lo5;
-          lmax = mpc_max(lmax, mpc_max(mpc_max(mpc_max(mpc_abs(dl0), mpc_abs(dl1)), mpc_max(mpc_abs(dl2), mpc_abs(dl3))), mpc_max(mpc_abs(dl4), mpc_abs(dl5))));
-        }
-        /* ---- trial: record k-1 ---- */
-        lam_t[0] = lo0 + alpha_l * dl0; lam_t[1] = lo1 + alpha_l * dl1; lam_t[2] = lo2 + alpha_l * dl2;
-        lam_t[3] = lo3 + alpha_l * dl3; lam_t[4] = lo4 + alpha_l * dl4; lam_t[5] = lo5 + alpha_l * dl5;
-        MPC_UNROLL
-        for (int i = 0; i < 6; i++) s_t[i] = s_o[i] + alpha * ds[i];
-        n_del_t = n_del_o + alpha * ddel;
-        n_acc_t = n_acc_o + alpha * dacc;
-        R rec[IT_SZ] = {};                           /* the trial record, stored group by group below */
-        MPC_UNROLL
-        for (int i = 0; i < 6; i += 2) {
-          rec[F_S + i] = s_t[i]; rec[F_S + i + 1] = s_t[i + 1];
-          rec[F_LAM + i] = lam_t[i]; rec[F_LAM + i + 1] = lam_t[i + 1];
-          Ev.lsum += mpc_abs(lam_t[i]) + mpc_abs(lam_t[i + 1]);
-        }
-        rec[F_U] = n_del_t; rec[F_U + 1] = n_acc_t;
-        ws.template store_run<F_S, F_ZL - F_S>(r, J, rec + F_S);      /* s, u, lam (+ padding) */
-        /* duals of psi_k, v_k, delta_{k-1}, a_{k-1} */
-        const R xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
-        const R xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
-        const R dxb[4] = {ds[2], ds[3], ddel, dacc};
-        const R lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
-        R zln[4], zun[4], prod = R(1.0);
-        MPC_UNROLL
-        for (int b = 0; b < 4; b++) {
-          const R islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
-          const R zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
-          const R dzl = mu * islo - zl - zl * islo * dxb[b];
-          const R dzu = mu * isuo - zu + zu * isuo * dxb[b];
-          const R sl = xn[b] - lo[b], su = hi[b] - xn[b];
-          if (!(sl > R(0.0)) || !(su > R(0.0))) Ev.ok = false;
-          const R isl = frcp1(sl), isu = frcp1(su);
-          R a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
-          /* kappa_sigma safeguard, W&B eq. (16) */
-          a = mpc_max(mpc_min(a, ksm * isl), ksi * isl);
-          c = mpc_max(mpc_min(c, ksm * isu), ksi * isu);
-          zln[b] = a; zun[b] = c;
-          Ev.zsum += a + c;
-          const R pl = sl * a, pu = su * c;
-          Ev.cmin = mpc_min(Ev.cmin, mpc_min(pl, pu)); Ev.cmax = mpc_max(Ev.cmax, mpc_max(pl, pu));
-          prod *= sl * su;
-        }
-        MPC_UNROLL
-        for (int b = 0; b < 4; b++) { rec[F_ZL + b] = zln[b]; rec[F_ZU + b] = zun[b]; }
-        ws.template store_run<F_ZL, 8>(r, J, rec + F_ZL);
-        Ev.L += flog(prod);
-        zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
-        n_zdl = zln[2]; n_zdu = zun[2]; n_zal = zln[3]; n_zau = zun[3];
-        /* objective terms of (s_k, u_{k-1}) */
-        const R dv = s_t[3] - vref;
-        Ev.f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
-      } else {
-        MPC_UNROLL
-        for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
 #if MPC_S0_VARIABLE
-        s_o[2] = p0; s_o[3] = v0k;
-        s_t[2] = trial_x0(p0, st[2], alpha); s_t[3] = trial_x0(v0k, st[3], alpha);
-        const R c2 = s_t[2] - st[2], c3 = s_t[3] - st[3];    /* residuals of the pinning rows of psi_0, v_0 */
-        if (c2 != R(0.0) || c3 != R(0.0)) {
-          Ev.theta += mpc_abs(c2) + mpc_abs(c3); Ev.cinf = mpc_max(Ev.cinf, mpc_max(mpc_abs(c2), mpc_abs(c3)));
-          const R slp = s_t[2] - yl, sup = yu - s_t[2], slv = s_t[3] - vl, suv = vu - s_t[3];
-          if (!(slp > R(0.0)) || !(sup > R(0.0)) || !(slv > R(0.0)) || !(suv > R(0.0))) Ev.ok = false;
-          /* barrier terms of (psi_0, v_0) RELATIVE to their values at the pinned point, which are constants of the merit
-           * function like the stage-0 cost.  (The cost's own dependence on v_0, w_v (v_0 - vref_0)^2, is left a constant:
-           * a pushed v_0 sits at Config::maxSpeed, where vref_0 is, so its slope there is ~0.) */
-          Ev.L += flog((slp * sup * slv * suv) * frcp((st[2] - yl) * (yu - st[2]) * (st[3] - vl) * (vu - st[3])));
-        }
-#endif
-      }
-      if (k < M) {
-        /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
-        LinR L;
-        linearise(s_t, del_t, acc_t, sn_t, L);
-        MPC_UNROLL
-        for (int i = 0; i < 6; i++) { Ev.theta += mpc_abs(L.c[i]); Ev.cinf = mpc_max(Ev.cinf, mpc_abs(L.c[i])); }
-        const R ddl = (k >= 1) ? del_t - n_del_t : R(0.0);          /* delta_k - delta_{k-1} */
-        const R ddn = (k + 1 < M) ? del_nx - del_t : R(0.0);        /* delta_{k+1} - delta_k */
-        if (k >= 1) Ev.f += wdd * ddl * ddl;
-        const R v = s_t[3], vdt = v * dt, Apv = del_t * dtLf, Bp = v * dtLf;
-        const R l25 = ln_t[2] + ln_t[5];
-        /* rows of u_k */
-        const R rd = df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
-        const R ra = -dt * ln_t[3] - zal_t + zau_t;
-        Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_abs(rd), mpc_abs(ra)));
-        /* rows of s_k (k>=1) with A_k of the trial point */
-        if (k >= 1) {
-          const R r0 = lam_t[0] - (ln_t[0] + L.fp * ln_t[4] - L.g1 * ln_t[5]);
-          const R r1 = lam_t[1] - (ln_t[1] - ln_t[4]);
-          const R r2 = lam_t[2] - (-vdt * L.sp * ln_t[0] + vdt * L.cp * ln_t[1] + l25) - zs0 + zs1;
-          const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] -
-                            (dt * L.cp * ln_t[0] + dt * L.sp * ln_t[1] + Apv * l25 + ln_t[3] + dt * L.se * ln_t[4]) - zs2 + zs3;
-          const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
-          const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
-          Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(r0), mpc_abs(r1)), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
-        }
-      } else {
-        /* terminal state rows */
-        const R r2 = lam_t[2] - zs0 + zs1;
-        const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
-        const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
-        const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5];
-        Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(lam_t[0]), mpc_abs(lam_t[1])), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
-      }
-      /* carry to step k-1 */
-      MPC_UNROLL
-      for (int i = 0; i < 6; i++) { sn_o[i] = s_o[i]; sn_t[i] = s_t[i]; ln_t[i] = lam_t[i]; }
-      del_nx = del_t;
-      del_t = n_del_t; acc_t = n_acc_t; zdl_t = n_zdl; zdu_t = n_zdu; zal_t = n_zal; zau_t = n_zau;
-      del_o = n_del_o; acc_o = n_acc_o; ddk = n_ddk; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5;
+    /* the record of the initial state's own rows (used by the last step): asked for here, so that it travels with the first stage record */
+    R c_l0 = 0, c_l1 = 0, c_l2 = 0, c_l3 = 0, c_l4 = 0, c_l5 = 0, c_zlp = 0, c_zup = 0, c_zlv = 0, c_zuv = 0;
+    if (s0_rows) {
+      c_l0 = s0_lam(I, 0); c_l1 = s0_lam(I, 1); c_l2 = s0_lam(I, 2); c_l3 = s0_lam(I, 3); c_l4 = s0_lam(I, 4); c_l5 = s0_lam(I, 5);
+      c_zlp = s0_z(I, 0, 0); c_zup = s0_z(I, 0, 1); c_zlv = s0_z(I, 1, 0); c_zuv = s0_z(I, 1, 1);
     }
+#endif
+    /* the step of a stage as a function of whether it is the last one (k = 0: the initial state's own rows, no record to
+     * fetch): the loop runs the general form, the epilogue the other, and neither carries the other's registers */
+    auto step_k = [&](auto kz_, const int k) {
+      constexpr bool KZ = decltype(kz_)::value;
+        const int bk = (M - k) & 1;                    /* buffer of record k-1 */
+        R s_o[6], s_t[6], lam_t[6] = {0, 0, 0, 0, 0, 0};
+        R zs0 = 0, zs1 = 0, zs2 = 0, zs3 = 0;     /* trial duals of psi_k, v_k: zl_psi, zu_psi, zl_v, zu_v */
+        R n_del_o = 0, n_acc_o = 0, n_ddk = 0, lo0 = 0, lo1 = 0, lo2 = 0, lo4 = 0, lo5 = 0;
+        R n_del_t = 0, n_acc_t = 0, n_zdl = 0, n_zdu = 0, n_zal = 0, n_zau = 0;
+        if constexpr (!KZ) {
+          if (k >= 2) {
+            ws.stage_fetch_it(bk ^ 1, k - 2, I);
+            ws.stage_fetch_d(bk ^ 1, k - 2);
+            if (k == M) ws.template stage_wait<STG_IT_OPS + STG_D_OPS>();
+            else ws.template stage_wait<STG_IT_OPS + STG_D_OPS + ST_TRIAL>();
+          } else ws.template stage_wait<0>();
+          const int r = k - 1;
+          R ds[6];
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) { s_o[i] = ws.sit(bk, r, I, F_S + i); ds[i] = ws.sx(bk, r, F_D, D_S + i); }
+          const R lo3 = ws.sit(bk, r, I, F_LAM + 3);
+          lo0 = ws.sit(bk, r, I, F_LAM + 0); lo1 = ws.sit(bk, r, I, F_LAM + 1); lo2 = ws.sit(bk, r, I, F_LAM + 2);
+          lo4 = ws.sit(bk, r, I, F_LAM + 4); lo5 = ws.sit(bk, r, I, F_LAM + 5);
+          n_del_o = ws.sit(bk, r, I, F_U + 0); n_acc_o = ws.sit(bk, r, I, F_U + 1);
+          const R ddel = ws.sx(bk, r, F_D, D_U + 0), dacc = ws.sx(bk, r, F_D, D_U + 1);
+          n_ddk = ddel;
+          if (r == 0) Ev.du0 = mpc_max(mpc_abs(ddel), mpc_abs(dacc));   /* the outputs' part of the step (termination polish) */
+          /* ---- costate: lam+_k ---- */
+          R dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
+          if (with_costate) {
+            R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+            state_terms(s_o[2], s_o[3], s_o[4], s_o[5], ws.sit(bk, r, I, F_ZL + 0), ws.sit(bk, r, I, F_ZU + 0),
+                        ws.sit(bk, r, I, F_ZL + 1), ws.sit(bk, r, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+            R n0, n1, n2, n3, n4, n5;
+            if (k == M) {
+              n0 = -(hxy * ds[0]);
+              n1 = -(hxy * ds[1]);
+              n2 = -(gp + (Hpp + dw) * ds[2]);
+              n3 = -(gv + (Hvv + dw) * ds[3]);
+              n4 = -(gc + (Hcc + dw) * ds[4]);
+              n5 = -(ge + (Hee + dw) * ds[5]);
+            } else {
+              const R v = s_o[3];
+              LinR L;
+              linearise(s_o, del_o, acc_o, sn_o, L);   /* the residual part is unused here and is eliminated */
+              const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+              const R vdt = v * dt, Apv = del_o * dtLf;
+              /* curvature of stage k */
+              const R Hxx = -lc * fpp + le * h3, Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
+              const R Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+              const R L25 = L2 + L5;
+              n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * ds[0];
+              n1 = L1 - L4 - hxy * ds[1];
+              n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds[2] - Hpv * ds[3];
+              n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * ds[2] -
+                   (Hvv + dw) * ds[3] - Hev * ds[5] - Hvd * ddk;
+              n4 = -gc - (Hcc + dw) * ds[4];
+              n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * ds[5] - Hev * ds[3];
+            }
+            L0 = n0; L1 = n1; L2 = n2; L3 = n3; L4 = n4; L5 = n5;
+            dl0 = L0 - lo0; dl1 = L1 - lo1; dl2 = L2 - lo2; dl3 = L3 - lo3; dl4 = L4 - lo4; dl5 = L5 - lo5;
+            lmax = mpc_max(lmax, mpc_max(mpc_max(mpc_max(mpc_abs(dl0), mpc_abs(dl1)), mpc_max(mpc_abs(dl2), mpc_abs(dl3))), mpc_max(mpc_abs(dl4), mpc_abs(dl5))));
+          }
+          /* ---- trial: record k-1 ---- */
+          lam_t[0] = lo0 + alpha_l * dl0; lam_t[1] = lo1 + alpha_l * dl1; lam_t[2] = lo2 + alpha_l * dl2;
+          lam_t[3] = lo3 + alpha_l * dl3; lam_t[4] = lo4 + alpha_l * dl4; lam_t[5] = lo5 + alpha_l * dl5;
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) s_t[i] = s_o[i] + alpha * ds[i];
+          n_del_t = n_del_o + alpha * ddel;
+          n_acc_t = n_acc_o + alpha * dacc;
+          R rec[IT_SZ] = {};                           /* the trial record, stored group by group below */
+          MPC_UNROLL
+          for (int i = 0; i < 6; i += 2) {
+            rec[F_S + i] = s_t[i]; rec[F_S + i + 1] = s_t[i + 1];
+            rec[F_LAM + i] = lam_t[i]; rec[F_LAM + i + 1] = lam_t[i + 1];
+            Ev.lsum += mpc_abs(lam_t[i]) + mpc_abs(lam_t[i + 1]);
+          }
+          rec[F_U] = n_del_t; rec[F_U + 1] = n_acc_t;
+          ws.template store_run<F_S, F_ZL - F_S>(r, J, rec + F_S);      /* s, u, lam (+ padding) */
+          /* duals of psi_k, v_k, delta_{k-1}, a_{k-1} */
+          const R xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
+          const R xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
+          const R dxb[4] = {ds[2], ds[3], ddel, dacc};
+          const R lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+          R zln[4], zun[4], prod = R(1.0);
+          MPC_UNROLL
+          for (int b = 0; b < 4; b++) {
+            const R islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
+            const R zl = ws.sit(bk, r, I, F_ZL + b), zu = ws.sit(bk, r, I, F_ZU + b);
+            const R dzl = mu * islo - zl - zl * islo * dxb[b];
+            const R dzu = mu * isuo - zu + zu * isuo * dxb[b];
+            const R sl = xn[b] - lo[b], su = hi[b] - xn[b];
+            if (!(sl > R(0.0)) || !(su > R(0.0))) Ev.ok = false;
+            const R isl = frcp1(sl), isu = frcp1(su);
+            R a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
+            /* kappa_sigma safeguard, W&B eq. (16) */
+            a = mpc_max(mpc_min(a, ksm * isl), ksi * isl);
+            c = mpc_max(mpc_min(c, ksm * isu), ksi * isu);
+            zln[b] = a; zun[b] = c;
+            Ev.zsum += a + c;
+            const R pl = sl * a, pu = su * c;
+            Ev.cmin = mpc_min(Ev.cmin, mpc_min(pl, pu)); Ev.cmax = mpc_max(Ev.cmax, mpc_max(pl, pu));
+            prod *= sl * su;
+          }
+          MPC_UNROLL
+          for (int b = 0; b < 4; b++) { rec[F_ZL + b] = zln[b]; rec[F_ZU + b] = zun[b]; }
+          ws.template store_run<F_ZL, 8>(r, J, rec + F_ZL);
+          Ev.L += flog(prod);
+          zs0 = zln[0]; zs1 = zun[0]; zs2 = zln[1]; zs3 = zun[1];
+          n_zdl = zln[2]; n_zdu = zun[2]; n_zal = zln[3]; n_zau = zun[3];
+          /* objective terms of (s_k, u_{k-1}) */
+          const R dv = s_t[3] - vref;
+          Ev.f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
+        } else {
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) { s_o[i] = st[i]; s_t[i] = st[i]; }
+#if MPC_S0_VARIABLE
+          s_o[2] = p0; s_o[3] = v0k;
+          s_t[2] = trial_x0(p0, st[2], alpha); s_t[3] = trial_x0(v0k, st[3], alpha);
+          const R c2 = s_t[2] - st[2], c3 = s_t[3] - st[3];    /* residuals of the pinning rows of psi_0, v_0 */
+          if (c2 != R(0.0) || c3 != R(0.0)) {
+            Ev.theta += mpc_abs(c2) + mpc_abs(c3); Ev.cinf = mpc_max(Ev.cinf, mpc_max(mpc_abs(c2), mpc_abs(c3)));
+            const R slp = s_t[2] - yl, sup = yu - s_t[2], slv = s_t[3] - vl, suv = vu - s_t[3];
+            if (!(slp > R(0.0)) || !(sup > R(0.0)) || !(slv > R(0.0)) || !(suv > R(0.0))) Ev.ok = false;
+            /* barrier terms of (psi_0, v_0) RELATIVE to their values at the pinned point, which are constants of the merit
+             * function like the stage-0 cost.  (The cost's own dependence on v_0, w_v (v_0 - vref_0)^2, is left a constant:
+             * a pushed v_0 sits at Config::maxSpeed, where vref_0 is, so its slope there is ~0.) */
+            Ev.L += flog((slp * sup * slv * suv) * frcp((st[2] - yl) * (yu - st[2]) * (st[3] - vl) * (vu - st[3])));
+          }
+          /* ---- the record of stage "-1": lam_0 (the multipliers of the pinning rows) and the bound duals of psi_0, v_0 ---- */
+          if (s0_rows) {
+            const R rsc0 = lsm ? R(0.0) : R(1.0);
+            const R ds2 = rsc0 * (st[2] - p0), ds3 = rsc0 * (st[3] - v0k);        /* ds_0 (zero unless a start value was pushed) */
+            R dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0, dl4 = 0, dl5 = 0;
+            if (with_costate) {
+              /* the state rows of stage 0, solved for lam+_0 exactly as the rows of the stages above are (k < M there) */
+              const R islp = frcp1(p0 - yl), isup = frcp1(yu - p0), islv = frcp1(v0k - vl), isuv = frcp1(vu - v0k);
+              const R mub = lsm ? R(0.0) : mu;
+              const R Hpp = lsm ? R(1.0) : c_zlp * islp + c_zup * isup;
+              const R Hvv = lsm ? R(1.0) : df * R(2.0) * (wv + wneg0) + c_zlv * islv + c_zuv * isuv;
+              const R Hee = lsm ? R(1.0) : df * R(2.0) * we0, Hcc = lsm ? R(1.0) : df * R(2.0) * wc0;
+              const R gp = mub * (isup - islp);
+              const R gv = df * R(2.0) * (wv * (v0k - vref0) + wneg0 * v0k) + mub * (isuv - islv);
+              const R ge = df * R(2.0) * we0 * s_o[5], gc = df * R(2.0) * wc0 * s_o[4];
+              const R v = s_o[3];
+              LinR L;
+              linearise(s_o, del_o, acc_o, sn_o, L);
+              const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1;
+              const R vdt = v * dt, Apv = del_o * dtLf;
+              const R Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
+              const R Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+              const R L25 = L2 + L5;
+              const R n0 = L0 + fp * L4 - g1 * L5;
+              const R n1 = L1 - L4;
+              const R n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds2 - Hpv * ds3;
+              const R n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * ds2 -
+                           (Hvv + dw) * ds3 - Hvd * ddk;
+              const R n4 = -gc;
+              const R n5 = vdt * ce * L4 - ge - Hev * ds3;
+              (void)Hee; (void)Hcc; (void)Hee2;
+              dl0 = n0 - c_l0; dl1 = n1 - c_l1; dl2 = n2 - c_l2; dl3 = n3 - c_l3; dl4 = n4 - c_l4; dl5 = n5 - c_l5;
+              lmax = mpc_max(lmax, mpc_max(mpc_max(mpc_max(mpc_abs(dl0), mpc_abs(dl1)), mpc_max(mpc_abs(dl2), mpc_abs(dl3))), mpc_max(mpc_abs(dl4), mpc_abs(dl5))));
+            }
+            lam_t[0] = c_l0 + alpha_l * dl0; lam_t[1] = c_l1 + alpha_l * dl1; lam_t[2] = c_l2 + alpha_l * dl2;
+            lam_t[3] = c_l3 + alpha_l * dl3; lam_t[4] = c_l4 + alpha_l * dl4; lam_t[5] = c_l5 + alpha_l * dl5;
+            MPC_UNROLL
+            for (int i = 0; i < 6; i++) { ws.it(M, J, F_LAM + i) = lam_t[i]; Ev.lsum += mpc_abs(lam_t[i]); }
+            R z0_t[4];
+            const R xo[2] = {p0, v0k}, xn[2] = {s_t[2], s_t[3]}, dxb[2] = {ds2, ds3}, lo[2] = {yl, vl}, hi[2] = {yu, vu};
+            MPC_UNROLL
+            for (int b = 0; b < 2; b++) {
+              const R islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
+              const R zl = b ? c_zlv : c_zlp, zu = b ? c_zuv : c_zup;
+              const R dzl = mu * islo - zl - zl * islo * dxb[b];
+              const R dzu = mu * isuo - zu + zu * isuo * dxb[b];
+              const R sl = xn[b] - lo[b], su = hi[b] - xn[b];
+              const R isl = frcp1(sl), isu = frcp1(su);
+              R a = zl + alpha_z * dzl, c = zu + alpha_z * dzu;
+              a = mpc_max(mpc_min(a, ksm * isl), ksi * isl);
+              c = mpc_max(mpc_min(c, ksm * isu), ksi * isu);
+              z0_t[2 * b] = a; z0_t[2 * b + 1] = c;
+              ws.it(M, J, F_ZL + b) = a; ws.it(M, J, F_ZU + b) = c;
+              Ev.zsum += a + c;
+              const R pl = sl * a, pu = su * c;
+              Ev.cmin = mpc_min(Ev.cmin, mpc_min(pl, pu)); Ev.cmax = mpc_max(Ev.cmax, mpc_max(pl, pu));
+            }
+            zs0 = z0_t[0]; zs1 = z0_t[1]; zs2 = z0_t[2]; zs3 = z0_t[3];
+          }
+#endif
+        }
+        if (KZ || k < M) {
+          /* ---- trial: transition k, (s_k, u_k) -> s_{k+1} ---- */
+          LinR L;
+          linearise(s_t, del_t, acc_t, sn_t, L);
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) { Ev.theta += mpc_abs(L.c[i]); Ev.cinf = mpc_max(Ev.cinf, mpc_abs(L.c[i])); }
+          const R ddl = !KZ ? del_t - n_del_t : R(0.0);          /* delta_k - delta_{k-1} */
+          const R ddn = (k + 1 < M) ? del_nx - del_t : R(0.0);        /* delta_{k+1} - delta_k */
+          if (!KZ) Ev.f += wdd * ddl * ddl;
+          const R v = s_t[3], vdt = v * dt, Apv = del_t * dtLf, Bp = v * dtLf;
+          const R l25 = ln_t[2] + ln_t[5];
+          /* rows of u_k */
+          const R rd = df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
+          const R ra = -dt * ln_t[3] - zal_t + zau_t;
+          Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_abs(rd), mpc_abs(ra)));
+#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+          if (getenv("MPC_TRACE_ROWS")) printf("      k=%d rows of u: %.3e %.3e   [delta %.17g grad %.12e Bp*l25 %.12e zl %.12e zu %.12e]\n", k, (double)rd, (double)ra, (double)del_t, (double)(df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn)), (double)(Bp * l25), (double)zdl_t, (double)zdu_t);
+#endif
+          /* rows of s_k (k>=1) with A_k of the trial point */
+#if MPC_S0_VARIABLE
+          if (!KZ || s0_rows) {
+            /* (k = 0: the rows of the initial state's own variables, with the i = 0 terms of the objective) */
+            const R gvk = !KZ ? wv * (s_t[3] - vref) : wv * (s_t[3] - vref0) + wneg0 * s_t[3];
+            const R wck = !KZ ? wc : wc0, wek = !KZ ? we : we0;
+#else
+          if (!KZ) {
+            const R gvk = wv * (s_t[3] - vref), wck = wc, wek = we;
+#endif
+            const R r0 = lam_t[0] - (ln_t[0] + L.fp * ln_t[4] - L.g1 * ln_t[5]);
+            const R r1 = lam_t[1] - (ln_t[1] - ln_t[4]);
+            const R r2 = lam_t[2] - (-vdt * L.sp * ln_t[0] + vdt * L.cp * ln_t[1] + l25) - zs0 + zs1;
+            const R r3 = df * R(2.0) * gvk + lam_t[3] -
+                              (dt * L.cp * ln_t[0] + dt * L.sp * ln_t[1] + Apv * l25 + ln_t[3] + dt * L.se * ln_t[4]) - zs2 + zs3;
+            const R r4 = df * R(2.0) * wck * s_t[4] + lam_t[4];
+            const R r5 = df * R(2.0) * wek * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
+            Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(r0), mpc_abs(r1)), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
+#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+            if (getenv("MPC_TRACE_ROWS")) printf("      k=%d rows of s: %.3e %.3e %.3e %.3e %.3e %.3e\n", k, (double)r0, (double)r1, (double)r2, (double)r3, (double)r4, (double)r5);
+            if (k == 0) printf("      rows of s_0: %.3e %.3e %.3e %.3e %.3e %.3e  (alpha %.6f alpha_z %.6f)\n", (double)r0, (double)r1, (double)r2, (double)r3, (double)r4, (double)r5, (double)alpha, (double)alpha_z);
+#endif
+          }
+        } else {
+          /* terminal state rows */
+          const R r2 = lam_t[2] - zs0 + zs1;
+          const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] - zs2 + zs3;
+          const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
+          const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5];
+          Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(lam_t[0]), mpc_abs(lam_t[1])), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
+        }
+        /* carry to step k-1 */
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) { sn_o[i] = s_o[i]; sn_t[i] = s_t[i]; ln_t[i] = lam_t[i]; }
+        del_nx = del_t;
+        del_t = n_del_t; acc_t = n_acc_t; zdl_t = n_zdl; zdu_t = n_zdu; zal_t = n_zal; zau_t = n_zau;
+        del_o = n_del_o; acc_o = n_acc_o; ddk = n_ddk; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5;
+    };
+    MPC_STAGE_LOOP
+    for (int k = M; k >= 1; --k) step_k(std::false_type(), k);
+    step_k(std::true_type(), 0);
     if (!(Ev.theta == Ev.theta) || !(Ev.f == Ev.f) || !(Ev.L == Ev.L) || !(Ev.dinf == Ev.dinf)) Ev.ok = false;
     return Ev;
   }
@@ -1262,7 +1391,12 @@ struct Solver {
   /* a pinned start value after a step of length alpha; exactly the pinned value once it has arrived */
   MPC_HD R trial_x0(R x0, R pinned, R alpha_) const { return x0 == pinned ? pinned : x0 + alpha_ * (pinned - x0); }
   MPC_HD R kkt_error(const EvalR &e, R mu_) const {
+#if MPC_S0_VARIABLE
+    /* (with the initial state's own rows: the reference's 6N rows; bounds of psi_i, v_i (i = 0..N-1), delta_i, a_i) */
+    const R m = s0_rows ? R(6.0) * (M + 1) : R(6.0) * M, nb = s0_rows ? R(8.0) * M + R(4.0) : R(8.0) * M;
+#else
     const R m = R(6.0) * M, nb = R(8.0) * M;
+#endif
     const R sd = mpc_max(IC::s_max, (e.lsum + e.zsum) / (m + nb)) / IC::s_max;
     const R sc = mpc_max(IC::s_max, e.zsum / nb) / IC::s_max;
     const R compl_ = mpc_max(mpc_abs(e.cmax - mu_), mpc_abs(e.cmin - mu_));
@@ -1359,9 +1493,16 @@ struct Solver {
     wv = w12[2]; wd = w12[3]; wdd = w12[4];
     vref = (R)speed_target(P, 0.0, P.max_speed);
     /* i = 0 terms: constants of the objective (their variables are fixed), MPC.cpp:71-92 */
-    const R wc0 = ((double)mpc_abs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
-    const R we0 = ((double)mpc_abs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
-    const R vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
+#if !MPC_S0_VARIABLE
+    R wc0, we0, vref0;
+#endif
+    wc0 = ((double)mpc_abs(st[4]) < P.cte_panic) ? w12[0] : w12[11];
+    we0 = ((double)mpc_abs(st[5]) > P.epsi_panic) ? w12[10] : w12[1];
+    vref0 = (R)speed_target(P, (double)st[2], P.max_speed);
+#if MPC_S0_VARIABLE
+    wneg0 = (st[3] < R(0.0)) ? w12[9] : R(0.0);
+    s0_rows = P.initial_state_rows != 0;
+#endif
     cost0 = wc0 * st[4] * st[4] + we0 * st[5] * st[5] + wv * (st[3] - vref0) * (st[3] - vref0);
     R g0 = mpc_max(mpc_abs(R(2.0) * wc0 * st[4]), mpc_abs(R(2.0) * we0 * st[5]));
     R gv0 = R(2.0) * wv * (st[3] - vref0);
@@ -1438,7 +1579,7 @@ struct Solver {
 
   /* The state of an unfinished instance between two passes with phase == PH_DIR (everything else lives in the
    * current iterate slot of the workspace or is recomputed by setup()): 36 values through an accessor a(q). */
-  enum { PARK_N = 37 };
+  enum { PARK_N = 47 };
   template <class A> MPC_HD void park(A a, int attempt, int it_total) const {
     a(0) = mu; a(1) = tau; a(2) = E.theta; a(3) = E.cinf; a(4) = E.f; a(5) = E.L; a(6) = E.dinf; a(7) = E.cmin; a(8) = E.cmax;
     a(9) = E.lsum; a(10) = E.zsum; a(11) = fth0; a(12) = fth1; a(13) = fth2; a(14) = fth3; a(15) = fph0; a(16) = fph1;
@@ -1448,8 +1589,17 @@ struct Solver {
     a(30) = out_step; a(31) = (R)n_polish; a(32) = out_prev; a(35) = R(0.0); a(36) = (R)acc_count;
 #if MPC_S0_VARIABLE
     a(33) = p0; a(34) = v0k;
+    if (s0_rows) {
+      const int Ic = it(cur);
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) a(37 + i) = s0_lam(Ic, i);
+      a(43) = s0_z(Ic, 0, 0); a(44) = s0_z(Ic, 0, 1); a(45) = s0_z(Ic, 1, 0); a(46) = s0_z(Ic, 1, 1);
+    } else {
+      for (int q = 37; q < 47; q++) a(q) = R(0.0);
+    }
 #else
     a(33) = R(0.0); a(34) = R(0.0);
+    for (int q = 37; q < 47; q++) a(q) = R(0.0);
 #endif
   }
   template <class A> MPC_HD void unpark(A a, int &attempt, int &it_total) {
@@ -1461,6 +1611,12 @@ struct Solver {
     attempt = (int)a(28); it_total = (int)a(29); out_step = a(30); n_polish = (int)a(31); out_prev = a(32); acc_count = (int)a(36);
 #if MPC_S0_VARIABLE
     p0 = a(33); v0k = a(34);
+    if (s0_rows) {
+      const int Ic = it(cur);
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) ws.it(M, Ic, F_LAM + i) = a(37 + i);
+      ws.it(M, Ic, F_ZL + 0) = a(43); ws.it(M, Ic, F_ZU + 0) = a(44); ws.it(M, Ic, F_ZL + 1) = a(45); ws.it(M, Ic, F_ZU + 1) = a(46);
+    }
 #endif
     iters = iter; phase = PH_DIR;
   }
@@ -1485,6 +1641,7 @@ struct Solver {
     phase = ls ? PH_LS : PH_EVAL0; iter = 0; ls_start = ls; tiny = false; n_polish = 0; acc_count = 0; no_restart = false; out_step = out_prev = IC::huge;
 #if MPC_S0_VARIABLE
     p0 = pushed(st[2], yl, yu); v0k = pushed(st[3], vl, vu);
+    if (s0_rows) s0_reset(IT0);
 #endif
     alpha = alpha_l = alpha_z = dw_cur = R(0.0);
     theta_max = theta_min = dw_last = R(0.0);
@@ -1606,6 +1763,7 @@ struct Solver {
     const EvalR T = costate_trial(dw_cur, alpha, alpha_l, alpha_z, phase != PH_EVAL0, lmax);
     if (phase == PH_EVAL0) {
       E = T; cur = 1 - cur;                       /* (a fresh start evaluates slot 0 into slot 1) */
+
       if (!E.ok) return MPC_STATUS_NUMERIC;
       if (!keep_theta) { theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta); }
       keep_theta = false;
@@ -1617,6 +1775,7 @@ struct Solver {
       /* estimates above constr_mult_init_max = 1000 are discarded: the start point is then evaluated as it is */
       if (lmax <= R(1000.0)) {
         E = T; cur = 1 - cur;
+
         if (!E.ok) return MPC_STATUS_NUMERIC;
         theta_max = R(1e4) * mpc_max(R(1.0), E.theta); theta_min = R(1e-4) * mpc_max(R(1.0), E.theta);
         phase = PH_DIR;

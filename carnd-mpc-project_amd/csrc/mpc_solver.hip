@@ -58,7 +58,7 @@ constexpr int64_t kLdsPerCu = 160 * 1024;
 constexpr int kMaxCuts = 4;         /* cuts of the multi-phase solve: up to 5 launches per batch */
 constexpr int kCounterInts = 16;    /* two counters per phase */
 constexpr int kCounterRing = 32;    /* counter blocks: solve call n uses block n % 32 and zeroes block (n + 16) % 32 for its next user */
-constexpr int kParkRows = 37;       /* Solver::PARK_N */
+constexpr int kParkRows = 47;       /* Solver::PARK_N */
 constexpr int kFinPromote = -2, kFinScratch = -3;   /* a lane that waits to hand its instance to the fp64 phase (promoted / to be solved from scratch) */
 constexpr int kTailMaxRing = 512;   /* deferred tails: batches whose stragglers may be outstanding at once */
 constexpr int kFreshRing = 24;      /* fresh queues: one per batch between its launch and the completion of the tail slice that absorbs its stragglers */
@@ -429,16 +429,17 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
       const int n = n_mv < n_fr ? n_mv : n_fr;
       if (n > 0) {
         ws.stage_drain();                        /* the trial sweep's stores have landed, the staging buffers are idle */
-        static_assert(!STAGING || staging_lds_bytes<R>() >= (size_t)(kParkRows + 2) * 64 * sizeof(double), "the mailbox must fit the staging buffers");
-        double *mb = smem;                       /* [kParkRows + 2][64]: Solver::park scalars, instance, passes */
+        static_assert(!STAGING || staging_lds_bytes<R>() >= (size_t)kParkRows * 64 * sizeof(R) + 2 * 64 * sizeof(int), "the mailbox must fit the staging buffers");
+        R *mb = (R *)smem;                       /* [kParkRows][64]: Solver::park scalars (in the solver's own precision) ... */
+        int *mi = (int *)(mb + kParkRows * 64);  /* ... [2][64]: instance, passes */
         const unsigned long long below = (1ull << threadIdx.x) - 1ull;
         const bool is_src = movable && __builtin_popcountll(mv & below) < n;
         const int my_f = __builtin_popcountll(fr & below);
         const bool is_dst = is_free && my_f < n;
         if (is_src) {
           const unsigned ln = threadIdx.x;
-          S.park([mb, ln](int q) -> double & { return mb[q * 64 + ln]; }, attempt, it_total);
-          mb[kParkRows * 64 + ln] = (double)i; mb[(kParkRows + 1) * 64 + ln] = (double)passes;
+          S.park([mb, ln](int q) -> R & { return mb[q * 64 + ln]; }, attempt, it_total);
+          mi[ln] = (int)i; mi[64 + ln] = passes;
           have = false;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
           unsigned long long m = mv;
           for (int r = 0; r < my_f; ++r) m &= m - 1ull;
           const int src = __builtin_ctzll(m);
-          i = (int64_t)mb[kParkRows * 64 + src]; passes = (int)mb[(kParkRows + 1) * 64 + src];
+          i = (int64_t)mi[src]; passes = mi[64 + src];
           R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
           for (int q = 0; q < 6; q++) st[q] = (R)state[q * ld + i];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_kernel(
             for (int q = 0; q < MPC_NW; q++) w[q] = (R)P.weights[q];
           }
           (void)S.setup(st, cf, (R)yaw_lo[i], (R)yaw_hi[i], w, false);
-          S.unpark([mb, src](int q) -> double { return mb[q * 64 + src]; }, attempt, it_total);
+          S.unpark([mb, src](int q) -> R { return mb[q * 64 + src]; }, attempt, it_total);
           const int I = S.cur ? FL::IT1 : FL::IT0;
           WS wsrc = ws;
           wsrc.lane = src;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_tail_slice_kernel(const MpcPa
       RIO *tb = (RIO *)__double_as_longlong(pm[4 * lp]);
       int32_t *st_arr = (int32_t *)__double_as_longlong(pm[5 * lp]), *it_arr = (int32_t *)__double_as_longlong(pm[6 * lp]);
       const int64_t l = (int64_t)pm[7 * lp];
-      /* an entry is 70 numbers that have travelled through one or more queues: what it says about where its results go is checked
+      /* an entry is 80 numbers that have travelled through one or more queues: what it says about where its results go is checked
        * before it is believed (a damaged one is reported to the host -- mpc_last_error -- instead of being written through) */
       if (!(slot >= 0 && slot < A.ring && i >= 0 && i < l && ob && st_arr && l > 0)) {
         __hip_atomic_store(A.res + 28, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1203,9 +1204,9 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
     MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
   } else MPC_CREATE_CHECK(hipFuncSetAttribute((const void *)mpc_solve_kernel<true, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-  h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32) * 64;   /* reals per wavefront tile */
-  h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true) * 64;
-  h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false) * 64;
+  h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32, p->initial_state_rows != 0) * 64;   /* reals per wavefront tile */
+  h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true, p->initial_state_rows != 0) * 64;
+  h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false, p->initial_state_rows != 0) * 64;
   h->mixed = wants_mixed(p);
   /* MPC_MIXED=0/1 overrides the parameter for every handle of the process: how the whole parity suite was run with the fp32
    * start forced on (tools/r03_session.sh p); a measurement aid, not an interface */
@@ -1218,7 +1219,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   {
     /* LDS-resident kernel: as many instances per workgroup as 160 KB hold (32, 16 or 8); one workgroup per CU */
-    const int64_t per_inst = mpc::workspace_fields_per_instance(p->N, f32) * (int64_t)(f32 ? sizeof(float) : sizeof(double));
+    const int64_t per_inst = mpc::workspace_fields_per_instance(p->N, f32, p->initial_state_rows != 0) * (int64_t)(f32 ? sizeof(float) : sizeof(double));
     for (int lanes : {32, 16, 8})
       if (lanes * per_inst <= kLdsPerCu) { h->lds_lanes = lanes; break; }
     /* Measured on MI355X (tools/batch_sweep.py, same box, B = 1 ... 16 384): the LDS-resident kernel is 5-9 % SLOWER than the
@@ -1296,7 +1297,9 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (wants_mixed(p) != h->mixed && !getenv("MPC_MIXED")) {
     g_last_error = "f32_finish / f64_f32_start cannot change on a live handle (they decide the workspaces)"; return MPC_ERR_INVALID;
   }
-  if (p->N != h->params.N || p->precision != h->params.precision) { g_last_error = "N and precision cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID; }
+  if (p->N != h->params.N || p->precision != h->params.precision || (p->initial_state_rows != 0) != (h->params.initial_state_rows != 0)) {
+    g_last_error = "N, precision and initial_state_rows cannot change on a live handle (they size the workspace)"; return MPC_ERR_INVALID;
+  }
   if (h->tail_ready && (p->tail_ring != h->params.tail_ring || p->tail_capacity != h->params.tail_capacity)) {
     g_last_error = "tail_ring and tail_capacity cannot change once the tail queue exists"; return MPC_ERR_INVALID;
   }
@@ -1374,7 +1377,7 @@ static int record_stats(MpcHandle *h, int64_t B, const int32_t *status, const in
 template <class R, int LANES>
 static int launch_lds_n(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const R *state, const R *coeffs, const R *yaw_lo,
                         const R *yaw_hi, const R *weights, R *out, R *traj, int32_t *status, int32_t *iters, hipStream_t s) {
-  const size_t lds = (size_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4) * sizeof(R) * LANES;
+  const size_t lds = (size_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4, h->params.initial_state_rows != 0) * sizeof(R) * LANES;
   const unsigned grid = (unsigned)((B + LANES - 1) / LANES);
   hipLaunchKernelGGL((mpc_solve_lds_kernel<R, LANES>), dim3(grid), dim3(kBlock), lds, s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
                      weights, out, traj, status, iters);

@@ -823,6 +823,8 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
       double r = df * g[i] - zl[i] + zu[i];
       for (int j = 0; j < m; j++) r += J[(size_t)j * n + i] * lam[j];
       dinf = fmax(dinf, fabs(r)); z1 += zl[i] + zu[i];
+      if (opt->verbose > 1 && (i % P->cfg->N) == 0 && i < 6 * P->cfg->N) fprintf(stderr, "      row of x_0[%d]: %.3e\n", i / P->cfg->N, r);
+      if (opt->verbose > 2 && i >= P->I.delta && i < P->I.a) fprintf(stderr, "      row of delta[%d]: %.3e  [delta %.17g grad %.12e JTlam %.12e zl %.12e zu %.12e]\n", i - P->I.delta, r, x[i], df * g[i], r - (df * g[i] - zl[i] + zu[i]), zl[i], zu[i]);
     }
     double sd = fmax(s_max, (l1 + z1) / (m + nb)) / s_max, sc = fmax(s_max, z1 / (nb > 0 ? nb : 1)) / s_max;
     double cmax = 0, cmin = DBL_MAX;   /* range of the complementarity products */
@@ -982,6 +984,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
     if (n_polish > 0) {   /* keep the converged iterate: the step about to be taken is a polish step */
       memcpy(x_keep, x, szn); memcpy(lam_keep, lam, szm); memcpy(zl_keep, zl, szn); memcpy(zu_keep, zu, szn); info_keep = *info;
     }
+    if (opt->verbose > 1) fprintf(stderr, "      step: alpha %.6f alpha_z %.6f\n", alpha, az);
     memcpy(x, xt, szn);
     out_step = alpha * fmax(fmax(fabs(dx[P->I.delta]), fabs(dx[P->I.a])), 0.03 * dxn);   /* outputs, and 0.03 x any primal variable (trajectory: 1e-5 m) */
     for (int j = 0; j < m; j++) lam[j] += alpha * dlam[j];

@@ -32,8 +32,8 @@ int main(int argc, char **argv) {
   OrcConfig cfg;
   if (orc_config_load(argv[1], &cfg) != 0) return 7;
   cfg.N = N; cfg.dt = dt;
-  std::vector<double> ws64((size_t)(N - 1) * mpc::Fields<double>::STAGE_SZ);
-  std::vector<float> ws32((size_t)(N - 1) * mpc::Fields<float>::STAGE_SZ);
+  std::vector<double> ws64((size_t)mpc::workspace_fields_per_instance(N, false, true));
+  std::vector<float> ws32((size_t)mpc::workspace_fields_per_instance(N, true, true));
   double worst64 = 0, worst32 = 0;
   int bad = 0;
   for (int i = 0; i < B; i++) {

@@ -20,7 +20,7 @@ static int twin_solve(const MpcParams *p, int64_t B, int64_t ld, const R *state,
                       const R *weights, R *out, R *traj, int32_t *status, int32_t *iters) {
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   const int N = p->N;
-  std::vector<R> wsbuf((size_t)(N - 1) * mpc::Fields<R>::STAGE_SZ);
+  std::vector<R> wsbuf((size_t)mpc::workspace_fields_per_instance(N, sizeof(R) == 4, true));
   for (int64_t i = 0; i < B; i++) {
     R st[6], cf[MPC_NCOEF], w[MPC_NW], o9[9];
     std::vector<R> tr(2 * N);
@@ -105,7 +105,7 @@ static int solve_parked_t(const MpcParams *p, int64_t B, int64_t ld, int pass_cu
   const int N = p->N, M = N - 1;
   using SV = mpc::Solver<mpc::HostWorkspace<R>, R>;
   using FD = mpc::Fields<R>;
-  std::vector<R> wsA((size_t)M * FD::STAGE_SZ), wsB((size_t)M * FD::STAGE_SZ, R(-7.0));
+  std::vector<R> wsA((size_t)(M + 1) * FD::STAGE_SZ), wsB((size_t)(M + 1) * FD::STAGE_SZ, R(-7.0));
   for (int64_t i = 0; i < B; i++) {
     R st[6], cf[MPC_NCOEF], w[MPC_NW];
     double park[SV::PARK_N];
@@ -184,8 +184,8 @@ static int solve_mixed_t(const MpcParams *p, int64_t B, int64_t ld, const RIO *s
   using SD = mpc::Solver<mpc::HostWorkspace<double>, double>;
   using FF = mpc::Fields<float>;
   using FD = mpc::Fields<double>;
-  std::vector<float> wsf((size_t)M * FF::STAGE_SZ);
-  std::vector<double> wsd((size_t)M * FD::STAGE_SZ);
+  std::vector<float> wsf((size_t)(M + 1) * FF::STAGE_SZ);
+  std::vector<double> wsd((size_t)(M + 1) * FD::STAGE_SZ);
   for (int64_t i = 0; i < B; i++) {
     float st[6], cf[MPC_NCOEF], w[MPC_NW];
     double std_[6], cfd[MPC_NCOEF], wd[MPC_NW], park[SF::PARK_N];
@@ -290,7 +290,7 @@ static int traffic_t(const MpcParams *p, int64_t B, int64_t ld, const R *state, 
   if (!p || p->N < 3 || p->N > MPC_MAX_N) return MPC_ERR_INVALID;
   using WS = CountingWorkspace<R>;
   using SV = mpc::Solver<WS, R>;
-  std::vector<R> wsbuf((size_t)(p->N - 1) * mpc::Fields<R>::STAGE_SZ);
+  std::vector<R> wsbuf((size_t)mpc::workspace_fields_per_instance(p->N, sizeof(R) == 4, true));
   for (int64_t i = 0; i < B; i++) {
     R st[6], cf[MPC_NCOEF], w[MPC_NW];
     for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];

@@ -123,6 +123,27 @@ def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torc
     assert 0.2 < rp["iters"].mean() - r["iters"].mean() < 1.0
 
 
+def test_initial_state_rows_on_the_device(pkg, host_twin, golden_dir, waypoints, torch_dev):
+    """MpcParams.initial_state_rows = 1 on the device: the iteration counts of the CPU build of the same solver (which are the
+    oracle's on all but 1-2 % of a batch, tests/test_host_twin.py), the oracle's statuses and points -- also in the mixed-precision
+    solve of a long horizon (the rows' multipliers cross from the fp32 to the fp64 solver with the parked scalars)."""
+    for config, over, B in (("config-fast.json", {}, 4096), ("config-stable.json", dict(N=25, dt=0.05), 1024)):
+        params = pkg.params_from_json(os.path.join(golden_dir, config), **over)
+        params.initial_state_rows = 1
+        b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=77)
+        r = gpu_solve(pkg, params, b, torch_dev)
+        q = params.copy(); q.f64_f32_start = 0
+        r0 = gpu_solve(pkg, q, b, torch_dev) if params.N >= 15 else r
+        tw = twin_solve(host_twin, q, b)
+        assert np.array_equal(r["status"], tw["status"]) and np.array_equal(r0["status"], tw["status"]) and (r["status"] == 0).all()
+        assert (r0["iters"] == tw["iters"]).mean() >= 0.99
+        assert np.max(np.abs(r0["out"][:8] - tw["out"][:8])) < 1e-8 and np.max(np.abs(r["out"][:8] - tw["out"][:8])) < 1e-6
+        idx = list(range(0, B, B // 64))
+        ref = oracle_solve_batch(O.load_config(config, **over), b, idx)
+        assert (r0["iters"][idx] == ref["iters"]).mean() >= 0.95
+        assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "initial_state_rows, %s" % config)
+
+
 def test_acceptable_level_termination_matches_oracle(pkg, host_twin, golden_dir, waypoints, torch_dev):
     """MPC_STATUS_ACCEPTABLE on the device (IPOPT's acceptable_tol / acceptable_iter, include/mpc_amd.h): with an acceptable level of
     1e-3 and two iterates in a row most instances of a batch stop a step or two short of convergence -- the same instances, after the
@@ -696,7 +717,7 @@ def test_horizon_extremes_match_oracle(pkg, golden_dir, waypoints, torch_dev, N,
     assert_parity(r["out"][:, idx], ref["out"], r["traj"][:, idx], ref["traj"], "N=%d" % N)
 
 
-@pytest.mark.parametrize("case", ["headline", "weights", "f32", "mixed", "N25", "N25plain"])
+@pytest.mark.parametrize("case", ["headline", "weights", "f32", "mixed", "N25", "N25plain", "rows"])
 def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_dev, case):
     """MpcParams.tail_cut: instances still running after `tail_cut` passes leave their launch (status PENDING at the bulk's
     completion) and are finished by the handle's tail launches; after mpc_tail_wait every array is bitwise what the single
@@ -709,6 +730,8 @@ def test_deferred_tails_are_bitwise_identical(pkg, golden_dir, waypoints, torch_
     assert params.f64_f32_start == 2                          # MPC_F32_START_AUTO, as shipped: long horizons ("N25") start on the fp32 record
     if case == "N25plain":
         params.f64_f32_start = 0                              # every iteration in fp64
+    if case == "rows":
+        params.initial_state_rows = 1                         # lam_0 and z_0 travel with a deferred instance (ten more parked values)
     f32 = case in ("f32", "mixed")
     if f32:
         params.precision = pkg.PRECISION_F32

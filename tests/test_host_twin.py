@@ -73,6 +73,34 @@ def test_termination_polish_pins_weakly_determined_outputs(pkg, host_twin, golde
     assert r["iters"][ok].mean() - rp["iters"][ok].mean() < 0.9          # N = 25; 0.43 on the N = 10 headline workload
 
 
+def test_initial_state_rows_follow_the_oracle_iteration_for_iteration(pkg, host_twin, golden_dir, waypoints):
+    """MpcParams.initial_state_rows (include/mpc_amd.h).  The reference's NLP keeps the initial state as six variables pinned by six
+    equality rows (MPC.cpp:116-121, 269-281); their multipliers and the bound duals of psi_0 / v_0 decouple from the Newton step,
+    so the device solver leaves them out by default -- and its dual infeasibility then lacks the residual those variables' rows keep
+    after a step the fraction-to-the-boundary rule has cut: on a few per cent of a batch its barrier parameter comes down an
+    iteration before the oracle's (same solution at the end).  With the rows carried the solver takes the oracle's iteration count
+    on all but 1-2 % of the instances (those differ by the rounding of the last step); every status and every point as before."""
+    import oracle_lib as O
+    from helpers import oracle_solve_batch
+    for sweep in (False, True):
+        params = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+        B = 768
+        b = pkg.scenarios.lake_track_batch(B, params, waypoints, seed=77)
+        w = pkg.scenarios.weight_sweep(B, params, seed=78, velocity_weights=(0.0, 1.0, 100.0)) if sweep else None
+        ref = oracle_solve_batch(O.load_config("config-fast.json"), b, range(B), weights=w)
+        same = {}
+        for rows in (0, 1):
+            q = params.copy(); q.initial_state_rows = rows
+            r = twin_solve(host_twin, q, b, weights=w)
+            assert np.array_equal(r["status"], ref["status"])
+            ok = r["status"] == 0
+            far = np.abs(r["out"][6] - ref["out"][6]) > 1e-6                  # (forks of a flat objective: velocity weight 0)
+            assert (ok & far).sum() <= (B // 200 if sweep else 0)
+            assert np.max(np.abs(r["out"][:8] - ref["out"][:8])[:, ok & ~far]) < 1e-6
+            same[rows] = float((r["iters"] == ref["iters"])[ok].mean())
+        assert same[1] >= 0.975 and same[1] >= same[0] + 0.01, same
+
+
 def test_instances_that_leave_the_central_path(pkg, host_twin, golden_dir, waypoints):
     """Where IPOPT would enter its restoration phase (src/control/MPC.cpp:290-292) and where the iteration cap strikes:
     named instances of the unfiltered draw.  The device solver (CPU build) and the oracle report the SAME status, the same

@@ -190,5 +190,28 @@ p)   # the round's evidence on the final build: full-scale soak, kernel trace an
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/r04p_pmc_sq -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-legs --full-json $OUT/r04p_pmc_sq.json > /dev/null 2> $OUT/r04p_pmc_sq.err; echo "pmc sq exit=$?" | tee -a $P
   cd $R
   ;;
+q)   # the initial state's own rows carried (lam_0, z_0): the whole GPU suite, then the rates
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $OUT/r04q_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r04q_pytest.log
+  run survey_k400 --steps 400
+  run filtered_c0 --steps 200 --population filtered --tail-cut 0
+  run survey_k400_b --steps 400
+  run n25_survey --steps 400 --N 25 --dt 0.05 --config config-stable.json --batch 32768 --inflight 4
+  ;;
+s)   # GPU suite after the initial_state_rows switch, then rates
+  export GPU_MAX_HW_QUEUES=8
+  timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $OUT/r04s_pytest.log 2>&1; echo "pytest exit=$?" | tee -a $P; tail -5 $OUT/r04s_pytest.log
+  run filtered_c0 --steps 200 --population filtered --tail-cut 0
+  run survey_k400 --steps 400
+  run filtered_c0_rows --steps 200 --population filtered --tail-cut 0 --initial-state-rows
+  ;;
+r)   # rates only
+  export GPU_MAX_HW_QUEUES=8
+  run filtered_c0 --steps 200 --population filtered --tail-cut 0
+  run survey_k400 --steps 400
+  run filtered_c0_b --steps 200 --population filtered --tail-cut 0
+  run filtered_c0_rows --steps 200 --population filtered --tail-cut 0 --initial-state-rows
+  run survey_k400_rows --steps 400 --initial-state-rows
+  ;;
 esac
 echo done | tee -a $P
