@@ -700,7 +700,7 @@ void orc_default_options(OrcSolveOptions *o) {
   o->bound_relax_factor = 1e-8; o->honor_original_bounds = 1;
   o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4;
   o->acceptable_tol = 1e-6; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
-  o->acceptable_compl_inf_tol = 1e-2; o->acceptable_iter = 15;
+  o->acceptable_compl_inf_tol = 1e-2; o->acceptable_iter = 15; o->max_soc = 0;
 }
 
 typedef struct Filter { double th[256], ph[256]; int n; } Filter;
@@ -739,6 +739,8 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   double *K = (double *)malloc(sizeof(double) * (size_t)nk * nk), *rhs = (double *)malloc(sizeof(double) * nk);
   double *sol = (double *)malloc(sizeof(double) * nk), *dx = sol, *dlam = sol + n;
   double *dzl = (double *)malloc(szn), *dzu = (double *)malloc(szn), *xt = (double *)malloc(szn), *ct = (double *)malloc(szm);
+  double *rhs_soc = (double *)malloc(sizeof(double) * nk), *sol_soc = (double *)malloc(sizeof(double) * nk);
+  double *csoc = (double *)malloc(szm), *cs = (double *)malloc(szm), *xs = (double *)malloc(szn);
   char *hl = (char *)malloc(n), *hu = (char *)malloc(n);
   double *x_keep = (double *)malloc(szn), *lam_keep = (double *)malloc(szm), *zl_keep = (double *)malloc(szn), *zu_keep = (double *)malloc(szn);
   OrcSolveInfo info_keep; memset(&info_keep, 0, sizeof(info_keep));
@@ -965,6 +967,61 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
         ftype = sw && armijo;   /* filter is augmented unless both hold (W&B step A-7) */
       }
       if (accepted) break;
+      /* second-order correction (W&B A-5.5 .. A-5.10; OrcSolveOptions.max_soc): only for the first trial point */
+      if (opt->max_soc > 0 && alpha == amax && theta_t >= theta_k) {
+        const double a0 = alpha;
+        double theta_old = theta_k, a_prev = a0;
+        for (int j = 0; j < m; j++) csoc[j] = a0 * c[j] + ct[j];
+        info->n_soc_tried++;
+        for (int p = 1; p <= opt->max_soc && !accepted; p++) {
+          for (int j = 0; j < m; j++) rhs_soc[n + j] = -csoc[j];
+          memcpy(rhs_soc, rhs, szn);
+          ldl_solve(&F, rhs_soc, sol_soc);
+          const double *dxs = sol_soc, *dls = sol_soc + n;
+          double as = 1;
+          for (int i = 0; i < n; i++) {
+            if (hl[i] && dxs[i] < 0) as = fmin(as, -tau * (x[i] - P->xl[i]) / dxs[i]);
+            if (hu[i] && dxs[i] > 0) as = fmin(as, tau * (P->xu[i] - x[i]) / dxs[i]);
+          }
+          for (int i = 0; i < n; i++) xs[i] = x[i] + as * dxs[i];
+          int ins = 1;
+          for (int i = 0; i < n; i++) if ((hl[i] && !(xs[i] - P->xl[i] > 0)) || (hu[i] && !(P->xu[i] - xs[i] > 0))) ins = 0;
+          if (!ins) break;
+          EVAL_C(xs, cs);
+          double theta_s = 0; for (int j = 0; j < m; j++) theta_s += fabs(cs[j]);
+          double phi_s = barrier_phi(P, xs, df * eval_f(P->cfg, &P->tape, xs), mu);
+          int acc_s = 0, ft_s = 0;
+          if (theta_s < theta_max && !filter_rejects(flt, theta_s, phi_s)) {
+            int sw = dphi < 0 && a0 * pow(-dphi, s_phi) > delta_sw * pow(theta_k, s_theta);
+            int armijo = phi_s - phi_k - eps_phi <= eta_phi * a0 * dphi;
+            if (theta_k <= theta_min && sw) { if (armijo) acc_s = 1; }
+            else if (theta_s <= (1 - gamma_theta) * theta_k || phi_s - phi_k - eps_phi <= -gamma_phi * theta_k) acc_s = 1;
+            ft_s = sw && armijo;
+          }
+          if (acc_s) {
+            /* the corrected step replaces the step: primal, multipliers and bound duals all come from it */
+            memcpy(xt, xs, szn);
+            for (int i = 0; i < n; i++) dx[i] = dxs[i];
+            for (int j = 0; j < m; j++) dlam[j] = dls[j];
+            for (int i = 0; i < n; i++) {
+              dzl[i] = hl[i] ? mu / (x[i] - P->xl[i]) - zl[i] - zl[i] / (x[i] - P->xl[i]) * dx[i] : 0;
+              dzu[i] = hu[i] ? mu / (P->xu[i] - x[i]) - zu[i] + zu[i] / (P->xu[i] - x[i]) * dx[i] : 0;
+            }
+            az = 1;
+            for (int i = 0; i < n; i++) {
+              if (hl[i] && dzl[i] < 0) az = fmin(az, -tau * zl[i] / dzl[i]);
+              if (hu[i] && dzu[i] < 0) az = fmin(az, -tau * zu[i] / dzu[i]);
+            }
+            alpha = as; accepted = 1; ftype = ft_s; info->n_soc_accepted++;
+            break;
+          }
+          if (theta_s > 0.99 * theta_old) break;                 /* kappa_soc: the correction has stopped reducing the violation */
+          for (int j = 0; j < m; j++) csoc[j] = as * csoc[j] + cs[j];
+          theta_old = theta_s; a_prev = as;
+        }
+        (void)a_prev;
+        if (accepted) break;
+      }
       alpha *= 0.5; info->n_backtracks++;
       if (alpha < amin) break;
     }
@@ -1019,6 +1076,7 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
   free(xl_rel); free(xu_rel);
   if (lam_out) memcpy(lam_out, lam, szm);
   free(lam); free(zl); free(zu); free(g); free(c); free(J); free(W); free(K); free(rhs); free(sol);
+  free(rhs_soc); free(sol_soc); free(csoc); free(cs); free(xs);
   free(dzl); free(dzu); free(xt); free(ct); free(hl); free(hu); free(F.perm); free(F.blk); free(flt);
   free(x_keep); free(lam_keep); free(zl_keep); free(zu_keep);
   return status;

@@ -114,6 +114,11 @@ typedef struct OrcSolveOptions {
   double dual_inf_tol, constr_viol_tol, compl_inf_tol;
   double acceptable_tol, acceptable_dual_inf_tol, acceptable_constr_viol_tol, acceptable_compl_inf_tol;
   int acceptable_iter;
+  /* IPOPT's second-order correction (W&B section 2.4; IPOPT default max_soc = 4, kappa_soc = 0.99): when the first trial point of
+   * a line search is rejected and its constraint violation is not below the current one, up to max_soc corrected steps
+   * (same matrix, constraint right-hand side alpha c(x) + c(x + alpha d)) are tried before the step is halved.  Default 0:
+   * NOT part of the restated algorithm (measured on SURVEY's populations: DESIGN.md section 3); an experiment switch. */
+  int max_soc;
 } OrcSolveOptions;
 
 typedef struct OrcSolveInfo {
@@ -129,6 +134,7 @@ typedef struct OrcSolveInfo {
   int n_backtracks;
   int acceptable_restored_older;   /* 1: STOP_AT_ACCEPTABLE returned a stored iterate that was not the current one */
   int no_restart;       /* 1: the line search failed at an almost feasible point: IPOPT does not try its restoration phase there */
+  int n_soc_tried, n_soc_accepted;   /* line searches that tried / accepted a second-order correction (max_soc > 0) */
 } OrcSolveInfo;
 
 void orc_default_options(OrcSolveOptions *opt);

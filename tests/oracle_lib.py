@@ -41,14 +41,14 @@ class OrcSolveOptions(C.Structure):
                 ("dual_inf_tol", C.c_double), ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double),
                 ("acceptable_tol", C.c_double), ("acceptable_dual_inf_tol", C.c_double),
                 ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
-                ("acceptable_iter", C.c_int)]
+                ("acceptable_iter", C.c_int), ("max_soc", C.c_int)]
 
 
 class OrcSolveInfo(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("kkt_error", C.c_double), ("mu", C.c_double),
                 ("obj", C.c_double), ("constr_viol", C.c_double), ("dual_inf", C.c_double),
                 ("compl_inf", C.c_double), ("n_regularised", C.c_int), ("n_backtracks", C.c_int),
-                ("acceptable_restored_older", C.c_int), ("no_restart", C.c_int)]
+                ("acceptable_restored_older", C.c_int), ("no_restart", C.c_int), ("n_soc_tried", C.c_int), ("n_soc_accepted", C.c_int)]
 
 
 class OrcRunPre(C.Structure):

@@ -243,3 +243,22 @@ def test_against_scipy_cross_solve_long_horizon_and_weights():
         # a0 is weakly determined in the interior: every case here has it on its bound
         assert abs(o9[6] - ref[6]) < 5e-6 and abs(o9[7] - ref[7]) < 5e-6, (cs["name"], o9[6], ref[6])
         assert np.max(np.abs(o9[:6] - ref[:6])) < 5e-5, cs["name"]
+
+
+def test_second_order_correction_is_inert_on_well_posed_instances():
+    """OrcSolveOptions.max_soc (default 0: the second-order correction is NOT part of the restated algorithm; DESIGN.md section 3 has
+    what it does to the hard instances of SURVEY's population).  On the well-posed instances the reference itself holds -- the
+    test.cpp scenario and its commented snapshots -- first trial points are accepted, so IPOPT's max_soc = 4 changes neither
+    status nor iteration count nor point."""
+    from helpers import TEST_CPP_COMMENTED
+    assert O.default_options().max_soc == 0
+    cfg = O.load_config("config-stable.json")
+    for sc in [TEST_CPP] + list(TEST_CPP_COMMENTED):
+        pre, _, _ = O.run_pre(cfg, sc["pose"], sc["ptsx"], sc["ptsy"])
+        cfg.yaw_low, cfg.yaw_high = pre.yaw_low, pre.yaw_high
+        res = {}
+        for soc in (0, 4):
+            st, o9, tx, ty, info = O.mpc_solve(cfg, list(pre.state), list(pre.coef)[:pre.nc], O.default_options(max_soc=soc))
+            res[soc] = (st, np.array(o9), info.iterations, info.n_soc_accepted)
+        assert res[0][0] == res[4][0] == 0 and res[4][3] == 0 and res[0][2] == res[4][2]
+        assert np.max(np.abs(res[0][1] - res[4][1])) < 1e-12
