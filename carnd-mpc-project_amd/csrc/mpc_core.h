@@ -1340,9 +1340,6 @@ struct Solver {
           const R rd = df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn) - Bp * l25 - zdl_t + zdu_t;
           const R ra = -dt * ln_t[3] - zal_t + zau_t;
           Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_abs(rd), mpc_abs(ra)));
-#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-          if (getenv("MPC_TRACE_ROWS")) printf("      k=%d rows of u: %.3e %.3e   [delta %.17g grad %.12e Bp*l25 %.12e zl %.12e zu %.12e]\n", k, (double)rd, (double)ra, (double)del_t, (double)(df * (R(2.0) * wd * del_t + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn)), (double)(Bp * l25), (double)zdl_t, (double)zdu_t);
-#endif
           /* rows of s_k (k>=1) with A_k of the trial point */
 #if MPC_S0_VARIABLE
           if (!KZ || s0_rows) {
@@ -1361,10 +1358,6 @@ struct Solver {
             const R r4 = df * R(2.0) * wck * s_t[4] + lam_t[4];
             const R r5 = df * R(2.0) * wek * s_t[5] + lam_t[5] - vdt * L.ce * ln_t[4];
             Ev.dinf = mpc_max(Ev.dinf, mpc_max(mpc_max(mpc_abs(r0), mpc_abs(r1)), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5)))));
-#if defined(MPC_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-            if (getenv("MPC_TRACE_ROWS")) printf("      k=%d rows of s: %.3e %.3e %.3e %.3e %.3e %.3e\n", k, (double)r0, (double)r1, (double)r2, (double)r3, (double)r4, (double)r5);
-            if (k == 0) printf("      rows of s_0: %.3e %.3e %.3e %.3e %.3e %.3e  (alpha %.6f alpha_z %.6f)\n", (double)r0, (double)r1, (double)r2, (double)r3, (double)r4, (double)r5, (double)alpha, (double)alpha_z);
-#endif
           }
         } else {
           /* terminal state rows */

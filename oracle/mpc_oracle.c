@@ -826,7 +826,6 @@ static int ipm_solve(Nlp *P, const OrcSolveOptions *opt, const double *xi, doubl
       for (int j = 0; j < m; j++) r += J[(size_t)j * n + i] * lam[j];
       dinf = fmax(dinf, fabs(r)); z1 += zl[i] + zu[i];
       if (opt->verbose > 1 && (i % P->cfg->N) == 0 && i < 6 * P->cfg->N) fprintf(stderr, "      row of x_0[%d]: %.3e\n", i / P->cfg->N, r);
-      if (opt->verbose > 2 && i >= P->I.delta && i < P->I.a) fprintf(stderr, "      row of delta[%d]: %.3e  [delta %.17g grad %.12e JTlam %.12e zl %.12e zu %.12e]\n", i - P->I.delta, r, x[i], df * g[i], r - (df * g[i] - zl[i] + zu[i]), zl[i], zu[i]);
     }
     double sd = fmax(s_max, (l1 + z1) / (m + nb)) / s_max, sc = fmax(s_max, z1 / (nb > 0 ? nb : 1)) / s_max;
     double cmax = 0, cmin = DBL_MAX;   /* range of the complementarity products */
