@@ -205,6 +205,16 @@ s)   # GPU suite after the initial_state_rows switch, then rates
   run survey_k400 --steps 400
   run filtered_c0_rows --steps 200 --population filtered --tail-cut 0 --initial-state-rows
   ;;
+v)   # the fp32 phase of the long-horizon solve at two waves per SIMD
+  export GPU_MAX_HW_QUEUES=8
+  N25="--N 25 --dt 0.05 --config config-stable.json --batch 32768"
+  run n25_occ1_i4 --steps 400 $N25 --inflight 4
+  MPC_F32_OCC=2 run n25_occ2_i4 --steps 400 $N25 --inflight 4
+  run n25_occ1_i8 --steps 400 $N25 --inflight 8
+  MPC_F32_OCC=2 run n25_occ2_i8 --steps 400 $N25 --inflight 8
+  MPC_F32_OCC=2 run n25_occ2_i8_filtered --steps 400 $N25 --inflight 8 --population filtered
+  run n25_occ1_i8_filtered --steps 400 $N25 --inflight 8 --population filtered
+  ;;
 r)   # rates only
   export GPU_MAX_HW_QUEUES=8
   run filtered_c0 --steps 200 --population filtered --tail-cut 0
