@@ -101,6 +101,7 @@ def parse_args(argv=None):
     ap.add_argument("--leg-tail-cut", type=int, default=None, help="override the tail cut of a leg that defers (measurement aid)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (the unfiltered population of the "
                     "headline workload and the other BASELINE.json configs)")
+    ap.add_argument("--leg-inflight", type=int, default=0, help="batches in flight of the extra legs (0: each leg's own, or the library's advice)")
     ap.add_argument("--leg", default="", help="run ONE extra leg of the default run alone in this process and print its JSON line (what the default "
                     "run starts as child processes): " + ", ".join(LEGS))
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of an extra leg that does not set its own")
@@ -126,8 +127,7 @@ def parse_args(argv=None):
                     "the CPU build of the solver header so that the multi-process plumbing can be exercised without a GPU; "
                     "the line it prints is marked as a stub and is not a measurement")
     args = ap.parse_args(argv)
-    if args.inflight <= 0:
-        args.inflight = 4 if args.precision == "f32" else 2
+    # (--inflight 0: the library's own advice for the workload, mpc_inflight_advice, once the parameters are known)
     if args.unfiltered:
         args.population = "unfiltered"
     if args.gather_group <= 0:
@@ -493,32 +493,32 @@ LEGS = {
     "filtered": ("the headline workload (configs[2]) drawn with the generator's own rejection sampling (instances the reference's road model does "
                  "not hold for are redrawn: yaw on its bound, waypoint windows that double back, fits beyond Config::maxFitError) -- rounds 1-3's headline; "
                  "no heavy tail (at most 26 iterations), tails not deferred",
-                 dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=2, population="filtered", tail_cut=0, steps=100)),
+                 dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=None, population="filtered", tail_cut=0, steps=100)),
     "headline_f32_start": ("the headline workload (survey population) with MpcParams.f64_f32_start = 1: the early iterations (barrier parameter above 2e-5) on the fp32 "
                            "record, every instance finished by the fp64 solver to the same tol and polish; four batches in flight",
-                           dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=100, f32_start=True)),
+                           dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=False, want_traj=True, nfl=None, population="survey", tail_cut=-1, steps=100, f32_start=True)),
     "configs_1": ("BASELINE.json configs[1]: 4 096 straight-line-offset states, config-stable.json",
-                  dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=8, steps=200,
+                  dict(config="config-stable.json", over={}, B=4096, kind="straight", f32=False, sweep=False, want_traj=True, nfl=None, steps=200,
                        note="a 4 096-instance launch is 64 waves, 6 % of the device: eight batches in flight")),
     "configs_3_share": ("BASELINE.json configs[3], one GPU's share of 262 144: 32 768 lake-track states, N=25 dt=0.05, fp64 handle as shipped (MPC_F32_START_AUTO: "
                         "horizons of 15 steps and more run their early iterations on the fp32 record, every instance finished by the fp64 solver), SURVEY 8d's "
                         "population, deferred tails, four batches in flight, windows of 400 batches",
-                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=400)),
+                        dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=None, population="survey", tail_cut=-1, steps=400)),
     "configs_3_share_filtered": ("the same share drawn with the generator's rejection sampling",
-                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, tail_cut=-1, steps=400)),
+                                 dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=None, tail_cut=-1, steps=400)),
     "configs_3_share_fp64_only": ("the same share (SURVEY 8d's population) with MpcParams.f64_f32_start = 0: every iteration in fp64 (bitwise the host twin's solve)",
-                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=4, population="survey", tail_cut=-1, steps=400,
+                                  dict(config="config-stable.json", over=dict(N=25, dt=0.05), B=32768, kind="lake", f32=False, sweep=False, want_traj=True, nfl=None, population="survey", tail_cut=-1, steps=400,
                                        f32_start=False)),
     "configs_4_share": ("BASELINE.json configs[4], one GPU's share of 1 048 576: 131 072 lake-track states (SURVEY 8d's population), fp32 mixed precision as shipped (fp32 "
                         "iterations down to the barrier parameter 2e-5, every instance finished in fp64), per-instance weight sweep (epsi / v incl. 0 / delta / a)",
-                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300, f32_refill=True)),
+                        dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=None, population="survey", tail_cut=-1, steps=300, f32_refill=True)),
     "configs_4_share_filtered": ("the same share drawn with the generator's rejection sampling",
-                                 dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, tail_cut=-1, steps=300, f32_refill=True)),
+                                 dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=None, tail_cut=-1, steps=300, f32_refill=True)),
     "configs_4_share_pure_fp32": ("the same share (SURVEY 8d's population) with the pure fp32 solver (f32_finish = 0: stops at tol_f32 = 5e-4, looser stated tolerances)",
-                                  dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300,
+                                  dict(config="config-fast.json", over={}, B=131072, kind="lake", f32=True, sweep=True, want_traj=False, nfl=None, population="survey", tail_cut=-1, steps=300,
                                        f32_pure=True)),
     "weights_sweep_f64": ("the fp64 solve of the configs[4] weight sweep (65 536 instances, SURVEY 8d's population): what the fp32 mode is to be compared with",
-                          dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=True, want_traj=False, nfl=4, population="survey", tail_cut=-1, steps=300)),
+                          dict(config="config-fast.json", over={}, B=65536, kind="lake", f32=False, sweep=True, want_traj=False, nfl=None, population="survey", tail_cut=-1, steps=300)),
 }
 
 
@@ -547,6 +547,8 @@ def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, c
         tail_cut, steps = 0, min(steps, 10)
     if args.leg_tail_cut is not None and tail_cut:
         tail_cut = args.leg_tail_cut
+    advised = pkg.inflight_advice(params, B)
+    nfl = args.leg_inflight or nfl or advised           # (nfl = None in LEGS: the library's advice, mpc_inflight_advice)
     pipe = Pipeline(pkg, torch, params, B, tens, t(w, tdt) if w is not None else None, want_traj, nfl, dev, local_rank, None, args,
                     tail_cut=tail_cut, tail_ring=args.tail_ring, outstanding=outstanding or args.outstanding or min(256, nfl * args.tail_ring))
     # (every handle's first calls allocate lazily -- second workspace, tail queues: they happen while the pipeline is primed)
@@ -557,6 +559,7 @@ def run_leg(pkg, torch, np, args, dev, local_rank, golden, wp, sync_all, name, c
     if tr["kernel_ms"]:
         r["kernel_ms_avg"] = float(np.mean(tr["kernel_ms"]))
     pipe.close()
+    r["batches_in_flight_advised"] = advised
     r.update({"workload": name, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "config": config, "N": params.N, "dt": params.dt, "dtype": "f32" if f32 else "f64", "trajectories": want_traj,
               "population": population, "draws": int(b["drawn"]), "rejected": b["rejected"]})
     if note:
@@ -628,7 +631,7 @@ def main():
     os.dup2(2, 1)
     # HIP serves 4 hardware queues per process by default; more streams in use than that need more (read at HIP start-up):
     # batches in flight, their tail streams, the gather stream, and the heavy-tailed legs of the default run
-    want_q = args.inflight * (2 if args.tail_cut else 1) + 1
+    want_q = (args.inflight if args.inflight > 0 else 4) * (2 if args.tail_cut else 1) + 1      # (--inflight 0: the library's advice, 2-8)
     if want_q > 4 or (not args.no_legs and world_env == 1 and not args.stub):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -684,6 +687,8 @@ def main():
         params.f64_f32_start = 0
     params.f32_phase_refill = 1 if args.f32_phase_refill else 0
     params.initial_state_rows = 1 if args.initial_state_rows else 0
+    if args.inflight <= 0:
+        args.inflight = pkg.inflight_advice(params, args.batch) if stub is None else 2
     if args.switch_mu > 0:
         params.mixed_switch_mu = args.switch_mu
     if args.tol_f32 > 0:

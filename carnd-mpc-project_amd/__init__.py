@@ -11,11 +11,11 @@ The directory is called ``carnd-mpc-project_amd`` (not importable as written);
 ``carnd_mpc_project_amd``.
 """
 from ._abi import (MpcParams, MpcBatchStats, MpcWireTelemetry, MpcError, library, library_path, build_library,
-                   params_default, params_from_json, STATUS_NAMES, PRECISION_F32, PRECISION_F64)
+                   params_default, params_from_json, inflight_advice, STATUS_NAMES, PRECISION_F32, PRECISION_F64)
 from .solver import BatchedMPC
 from . import scenarios
 from . import sharding
 
 __all__ = ["MpcParams", "MpcBatchStats", "MpcWireTelemetry", "MpcError", "library", "library_path", "build_library",
-           "params_default", "params_from_json", "BatchedMPC", "scenarios", "sharding", "STATUS_NAMES",
+           "params_default", "params_from_json", "inflight_advice", "BatchedMPC", "scenarios", "sharding", "STATUS_NAMES",
            "PRECISION_F32", "PRECISION_F64"]

@@ -74,7 +74,7 @@ EXPORTS = ["mpc_params_default", "mpc_params_load_json", "mpc_create", "mpc_set_
            "mpc_telemetry_batch_device", "mpc_rollout_batch_device", "mpc_debug_math_ext",
            "mpc_solve_batch_device_f32", "mpc_wire_parse", "mpc_wire_format_steer", "mpc_wire_format_manual",
            "mpc_wire_telemetry_batch_host", "mpc_debug_tile_pool", "mpc_telemetry_batch_host", "mpc_handle_device",
-           "mpc_run_batch_host", "mpc_last_batch_id", "mpc_tail_poll", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32"]
+           "mpc_run_batch_host", "mpc_last_batch_id", "mpc_tail_poll", "mpc_tail_wait", "mpc_tail_stream_wait", "mpc_tail_flush", "mpc_tail_pending", "mpc_tail_info", "mpc_solve_batch_host_f32", "mpc_inflight_advice"]
 
 _lib = None
 
@@ -133,6 +133,8 @@ def library():
     L.mpc_rollout_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [DP] * 8 + [C.c_void_p]
     L.mpc_telemetry_batch_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, DP, C.c_double] + [DP] * 4
     L.mpc_handle_device.argtypes = [C.c_void_p]
+    L.mpc_inflight_advice.argtypes = [C.c_void_p, C.c_int64]
+    L.mpc_inflight_advice.restype = C.c_int
     L.mpc_last_batch_id.argtypes = [C.c_void_p]
     L.mpc_last_batch_id.restype = C.c_int64
     L.mpc_tail_wait.argtypes = [C.c_void_p, C.c_int64]
@@ -163,6 +165,11 @@ def params_default():
     p = MpcParams()
     check(library().mpc_params_default(C.byref(p)), "mpc_params_default")
     return p
+
+
+def inflight_advice(params, B):
+    """mpc_inflight_advice: batches of B instances to keep in flight for these parameters."""
+    return int(library().mpc_inflight_advice(C.byref(params), int(B)))
 
 
 def params_from_json(path, **overrides):

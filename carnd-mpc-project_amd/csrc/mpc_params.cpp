@@ -161,3 +161,10 @@ extern "C" int mpc_params_load_json(const char *path, MpcParams *p) {
                                                : mph2mps(p->yaw_change_speeds[i]) * speed_scale;
   return ok ? MPC_OK : MPC_ERR_IO;
 }
+
+extern "C" int mpc_inflight_advice(const MpcParams *p, int64_t B) {
+  if (!p) return MPC_ERR_INVALID;
+  if (B > 0 && B < 16384) return 8;
+  if (p->precision == MPC_PRECISION_F32 || p->N >= MPC_F32_START_AUTO_N || p->f64_f32_start == MPC_F32_START_ON) return 4;
+  return 2;
+}

@@ -115,3 +115,17 @@ def test_params_from_json_against_a_third_reader(pkg, golden_dir, name):
         assert n_tab == len(j[key]) and list(tab)[:n_tab] == j[key]
         want = [mph(s) * scale if scale > 1 else min(mph(s), mph(j["max speed"])) for s in j[skey]]
         assert n_stab == len(want) and np.allclose(list(stab)[:n_stab], want, rtol=1e-15)
+
+
+def test_inflight_advice(pkg, golden_dir):
+    """mpc_inflight_advice: 8 for launches that do not fill the device, 4 for two-launch solves and long horizons, 2 for the
+    single-phase fp64 solve of a short horizon (what bench.py runs its workloads with)."""
+    import os
+    p = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
+    assert pkg.inflight_advice(p, 65536) == 2 and pkg.inflight_advice(p, 4096) == 8
+    q = p.copy(); q.precision = pkg.PRECISION_F32
+    assert pkg.inflight_advice(q, 131072) == 4
+    q = p.copy(); q.N = 25
+    assert pkg.inflight_advice(q, 32768) == 4
+    q = p.copy(); q.f64_f32_start = 1
+    assert pkg.inflight_advice(q, 65536) == 4

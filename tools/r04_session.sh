@@ -215,6 +215,14 @@ v)   # the fp32 phase of the long-horizon solve at two waves per SIMD
   MPC_F32_OCC=2 run n25_occ2_i8_filtered --steps 400 $N25 --inflight 8 --population filtered
   run n25_occ1_i8_filtered --steps 400 $N25 --inflight 8 --population filtered
   ;;
+w)   # the legs with the library's in-flight advice; the fp64 weight sweep with 2 and 4 in flight
+  export GPU_MAX_HW_QUEUES=8
+  for n in 2 4; do
+    timeout -k 10 300 python bench.py --leg weights_sweep_f64 --leg-inflight $n > $OUT/r04w_ws_$n.json 2> $OUT/r04w_ws_$n.err; echo "weights_sweep_f64 inflight $n exit=$?" | tee -a $P
+    python -c "import json; l = json.load(open('$OUT/r04w_ws_$n.json')); print('   %.2f M (strict %.2f) in flight %d advised %d' % (l['solves_per_s'] / 1e6, l['strict_solves_per_s'] / 1e6, l['batches_in_flight'], l['batches_in_flight_advised']))" | tee -a $P
+  done
+  run head_default --steps 200
+  ;;
 r)   # rates only
   export GPU_MAX_HW_QUEUES=8
   run filtered_c0 --steps 200 --population filtered --tail-cut 0
