@@ -164,7 +164,11 @@ extern "C" int mpc_params_load_json(const char *path, MpcParams *p) {
 
 extern "C" int mpc_inflight_advice(const MpcParams *p, int64_t B) {
   if (!p) return MPC_ERR_INVALID;
-  if (B > 0 && B < 16384) return 8;
-  if (p->precision == MPC_PRECISION_F32 || p->N >= MPC_F32_START_AUTO_N || p->f64_f32_start == MPC_F32_START_ON) return 4;
-  return 2;
+  /* two devices' worth of lanes in flight (131 072 instances: measured at N = 10, 8 192 .. 65 536 per launch, 8 x 16 384 and
+   * 4 x 32 768 give what 2 x 65 536 gives), between 2 and 8 launches; two-launch solves and long horizons at least 4 */
+  int64_t n = B > 0 ? (131072 + B - 1) / B : 8;
+  if (n < 2) n = 2;
+  if (n > 8) n = 8;
+  if ((p->precision == MPC_PRECISION_F32 || p->N >= MPC_F32_START_AUTO_N || p->f64_f32_start == MPC_F32_START_ON) && n < 4) n = 4;
+  return (int)n;
 }

@@ -372,10 +372,10 @@ int mpc_wire_telemetry_batch_host(MpcHandle *h, int64_t B, const MpcWireTelemetr
  * more than half full, new batches run without deferral (counted in mpc_tail_info).
  * The run(), telemetry, rollout and host entry points never defer. */
 int64_t mpc_last_batch_id(const MpcHandle *h);
-/* How many batches of B instances to keep in flight (handles on streams of their own, include/ INTEGRATION.md "batches in flight")
- * for these parameters, from the measurements behind DESIGN.md sections 6b/6c/6f: a launch that does not fill the device wants
- * company (8 below 16 384 instances), two-launch solves (MPC_PRECISION_F32, the fp32 start of long horizons) and horizons of 15
- * steps and more 4, the single-phase fp64 solve of a short horizon 2.  No device is touched. */
+/* How many batches of B instances to keep in flight (handles on streams of their own, INTEGRATION.md "batches in flight") for
+ * these parameters, from the measurements behind DESIGN.md sections 6b/6c/6f: about two devices' worth of lanes (131 072
+ * instances), between 2 and 8 launches -- 8 x 16 384 and 4 x 32 768 give what 2 x 65 536 gives -- and at least 4 for two-launch
+ * solves (MPC_PRECISION_F32, the fp32 start) and horizons of 15 steps and more.  No device is touched. */
 int mpc_inflight_advice(const MpcParams *p, int64_t B);
 int mpc_tail_poll(MpcHandle *h, int64_t batch_id);
 int mpc_tail_wait(MpcHandle *h, int64_t batch_id);

@@ -118,11 +118,11 @@ def test_params_from_json_against_a_third_reader(pkg, golden_dir, name):
 
 
 def test_inflight_advice(pkg, golden_dir):
-    """mpc_inflight_advice: 8 for launches that do not fill the device, 4 for two-launch solves and long horizons, 2 for the
-    single-phase fp64 solve of a short horizon (what bench.py runs its workloads with)."""
+    """mpc_inflight_advice: two devices' worth of lanes in flight, 2 .. 8 launches, at least 4 for two-launch solves and long
+    horizons (what bench.py runs its workloads with)."""
     import os
     p = pkg.params_from_json(os.path.join(golden_dir, "config-fast.json"))
-    assert pkg.inflight_advice(p, 65536) == 2 and pkg.inflight_advice(p, 4096) == 8
+    assert pkg.inflight_advice(p, 65536) == 2 and pkg.inflight_advice(p, 4096) == 8 and pkg.inflight_advice(p, 32768) == 4 and pkg.inflight_advice(p, 16384) == 8
     q = p.copy(); q.precision = pkg.PRECISION_F32
     assert pkg.inflight_advice(q, 131072) == 4
     q = p.copy(); q.N = 25

@@ -223,6 +223,28 @@ w)   # the legs with the library's in-flight advice; the fp64 weight sweep with 
   done
   run head_default --steps 200
   ;;
+z)   # where the fp32 start pays at N = 10: launches that do not fill the device
+  export GPU_MAX_HW_QUEUES=8
+  for b in 4096 16384 32768; do
+    run n10_b${b}_plain --steps 400 --batch $b --tail-cut 0 --population filtered
+    run n10_b${b}_f32start --steps 400 --batch $b --tail-cut 0 --population filtered --f64-f32-start
+  done
+  ;;
+y)   # batches in flight for launches of 8 192 .. 32 768 instances (N = 10, single-phase fp64)
+  export GPU_MAX_HW_QUEUES=8
+  for b in 8192 16384 32768; do
+    for n in 2 4 8; do run n10_b${b}_i$n --steps 400 --batch $b --tail-cut 0 --population filtered --inflight $n; done
+  done
+  run n10_b65536_i4 --steps 200 --tail-cut 0 --population filtered --inflight 4
+  ;;
+x)   # small launches with 8 / 16 / 32 in flight
+  export GPU_MAX_HW_QUEUES=8
+  for b in 4096 8192; do
+    for n in 8 16 32; do run n10_b${b}_i$n --steps 600 --batch $b --tail-cut 0 --population filtered --inflight $n; done
+  done
+  run n10_b1024_i16 --steps 600 --batch 1024 --tail-cut 0 --population filtered --inflight 16
+  run n10_b1024_i32 --steps 600 --batch 1024 --tail-cut 0 --population filtered --inflight 32
+  ;;
 r)   # rates only
   export GPU_MAX_HW_QUEUES=8
   run filtered_c0 --steps 200 --population filtered --tail-cut 0
