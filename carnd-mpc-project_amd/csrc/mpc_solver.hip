@@ -1118,9 +1118,13 @@ static void set_cuts(MpcHandle *h, const MpcParams *p) {
 /* two phases per solve (fp32 iterations, fp64 finish)?  F32 handles: f32_finish; F64 handles: f64_f32_start = 1, or 2
  * (MPC_F32_START_AUTO; the default is 0 = off) from the horizon at which the workspace of a full device no longer lives in the
  * Infinity Cache */
-static bool wants_mixed(const MpcParams *p) {
+static bool wants_mixed(const MpcParams *p, int64_t max_batch) {
   if (p->precision == MPC_PRECISION_F32) return p->f32_finish != 0;
-  return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && p->N >= MPC_F32_START_AUTO_N);
+  /* AUTO: long horizons (the workspace of a full device is in HBM proper: the fp32 record's bytes pay), and handles of one
+   * wavefront at most -- a lone wave is bound by the instructions it issues, and the fp32 solver's light math issues fewer:
+   * one MPC::solve() (B = 1, N = 10) 0.53 instead of 0.68 ms.  Not in between: at 4 096 instances per launch the second
+   * launch costs more than the fp32 phase saves (13.1 against 17.8 M solves/s). */
+  return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && (p->N >= MPC_F32_START_AUTO_N || max_batch <= MPC_F32_START_AUTO_MAX_BATCH));
 }
 
 static int validate_params(const MpcParams *p) {
@@ -1207,7 +1211,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   h->ws_stride = mpc::workspace_fields_per_instance(p->N, f32, p->initial_state_rows != 0) * 64;   /* reals per wavefront tile */
   h->ws_stride_f32 = mpc::workspace_fields_per_instance(p->N, true, p->initial_state_rows != 0) * 64;
   h->ws_stride_f64 = mpc::workspace_fields_per_instance(p->N, false, p->initial_state_rows != 0) * 64;
-  h->mixed = wants_mixed(p);
+  h->mixed = wants_mixed(p, max_batch);
   /* MPC_MIXED=0/1 overrides the parameter for every handle of the process: how the whole parity suite was run with the fp32
    * start forced on (tools/r03_session.sh p); a measurement aid, not an interface */
   if (const char *e = getenv("MPC_MIXED")) h->mixed = atoi(e) != 0;
@@ -1294,7 +1298,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   if (!h) return MPC_ERR_INVALID;
   int rc = validate_params(p);
   if (rc != MPC_OK) return rc;
-  if (wants_mixed(p) != h->mixed && !getenv("MPC_MIXED")) {
+  if (wants_mixed(p, h->max_batch) != h->mixed && !getenv("MPC_MIXED")) {
     g_last_error = "f32_finish / f64_f32_start cannot change on a live handle (they decide the workspaces)"; return MPC_ERR_INVALID;
   }
   if (p->N != h->params.N || p->precision != h->params.precision || (p->initial_state_rows != 0) != (h->params.initial_state_rows != 0)) {

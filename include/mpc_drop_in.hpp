@@ -116,12 +116,13 @@ struct Config {
   /* solver controls that have no counterpart among the reference's statics */
   inline static int maxIterations = 200;
   inline static double tolerance = 1e-8;
-  /* One MPC::solve() per telemetry message is a single serial chain on the device, and a lone wave issues fp32 work four
-   * times as fast as fp64: with the early iterations on the fp32 record (MpcParams.f64_f32_start; every solve still finished
-   * by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes 0.54 ms instead of 0.70 ms -- unless its
-   * hand-over is not clean (hard instances), in which case the solve starts again in fp64 and takes longer than the single-phase
-   * one.  Off by default: the single-phase solve is the reference behaviour (include/mpc_amd.h). */
-  inline static int fp32Start = 0;
+  /* One MPC::solve() per telemetry message is a single serial chain on the device: a lone wave is bound by the instructions it
+   * issues, and the fp32 solver's light math issues fewer.  With the early iterations on the fp32 record
+   * (MpcParams.f64_f32_start; every solve still finished by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes
+   * 0.53 ms instead of 0.68 ms -- unless its hand-over is not clean (hard instances), in which case the solve starts again in
+   * fp64 and takes longer than the all-fp64 one.  2 (default) = the library's own choice, MPC_F32_START_AUTO: handles of one
+   * wavefront at most, like this class's, and long horizons start on the fp32 record; 0 = every iteration in fp64; 1 = always. */
+  inline static int fp32Start = 2;
 
   /* Config::load(fileName), Config.cpp:31-87 (parsing and unit conversion live behind the C ABI) */
   static void load(const std::string &fileName) {
@@ -146,7 +147,7 @@ struct Config {
     p.max_acceleration = maxAcceleration; p.max_deceleration = maxDeceleration; p.max_speed = maxSpeed;
     p.steer_adj_thresh = steerAdjustmentThresh; p.steer_adj_ratio = steerAdjustmentRatio; p.Lf = Lf;
     p.cte_panic = ctePanic; p.epsi_panic = epsiPanic; p.max_iter = maxIterations; p.tol = tolerance;
-    p.f64_f32_start = fp32Start ? 1 : 0;
+    p.f64_f32_start = fp32Start == 1 ? MPC_F32_START_ON : (fp32Start == 0 ? MPC_F32_START_OFF : MPC_F32_START_AUTO);
     for (int i = 0; i < MPC_NW; i++) p.weights[i] = i < (int)weights.size() ? weights[i] : 0.0;
     auto put = [](const std::vector<double> &v, double *dst, int32_t &n) {
       n = (int32_t)(v.size() < MPC_MAX_TABLE ? v.size() : MPC_MAX_TABLE);
