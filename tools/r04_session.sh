@@ -245,6 +245,13 @@ x)   # small launches with 8 / 16 / 32 in flight
   run n10_b1024_i16 --steps 600 --batch 1024 --tail-cut 0 --population filtered --inflight 16
   run n10_b1024_i32 --steps 600 --batch 1024 --tail-cut 0 --population filtered --inflight 32
   ;;
+u)   # long windows on the final build: the pipeline over several seconds
+  export GPU_MAX_HW_QUEUES=8
+  run survey_k3000 --steps 3000
+  run n25_k1500 --steps 1500 --N 25 --dt 0.05 --config config-stable.json --batch 32768
+  timeout -k 10 300 python bench.py --leg configs_4_share --leg-steps 1000 > $OUT/r04u_c4.json 2> $OUT/r04u_c4.err; echo "configs_4_share exit=$?" | tee -a $P
+  python -c "import json; l = json.load(open('$OUT/r04u_c4.json')); print('   configs_4_share %.2f M (strict %.2f) %s in flight %d' % (l['solves_per_s'] / 1e6, l['strict_solves_per_s'] / 1e6, l['status_counts'], l['batches_in_flight']))" | tee -a $P
+  ;;
 r)   # rates only
   export GPU_MAX_HW_QUEUES=8
   run filtered_c0 --steps 200 --population filtered --tail-cut 0
