@@ -338,6 +338,18 @@ MPC_HD double frcp(double x) {
   return 1.0 / x;
 #endif
 }
+/* the value lane `lane` (wave-uniform) holds, in every lane: v_readlane_b32 per 32 bits (one instance per wavefront) */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double wave_bcast(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float wave_bcast(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+#else
+inline double wave_bcast(double x, int) { return x; }
+inline float wave_bcast(float x, int) { return x; }
+#endif
+
 MPC_HD double frcp1(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
@@ -606,7 +618,9 @@ struct Lin {
   R c[6];
 };
 
-template <class WS, class R>
+/* WAVE = true: one instance per wavefront (mpc_solve_wave_kernel): every lane runs this state machine on the same instance,
+ * `wlane` is the lane's number, and the sweeps that have a wave form share their stages between the lanes */
+template <class WS, class R, bool WAVE = false>
 struct Solver {
   using F = Fields<R>;
   using IC = IpmConst<R>;
@@ -619,6 +633,7 @@ struct Solver {
   static constexpr int ST_BACKWARD = F::ST_BACKWARD, ST_FORWARD = F::ST_FORWARD, ST_TRIAL = F::ST_TRIAL;
   const MpcParams &P;
   WS ws;
+  int wlane = 0;
   /* instance data */
   R st[6], coef[MPC_NCOEF], yl, yu;
   R wc, we, wv, wd, wdd, vref, cost0;
@@ -985,7 +1000,106 @@ struct Solver {
   /* ------------------------------------------------------------------ */
   /* forward sweep: Newton direction ds, du; step limits; dphi           */
   /* ------------------------------------------------------------------ */
+  /* The forward sweep with one instance per wavefront: lane k prepares stage k -- model, gains, reciprocal slacks: what costs -- for
+   * all stages at once; the recursion ds_k -> ds_{k+1} then runs through the lanes in order, each lane doing its stage's few
+   * dozen multiply-adds on the state the lane before it broadcast (the statements of forward(), in their order: same bits). */
+  MPC_HD void forward_wave() {
+    const int I = it(cur), J = it(1 - cur);
+    const bool mine = wlane < M;
+    const int k = mine ? wlane : M - 1;             /* (the lanes behind the last stage repeat it; nothing of theirs is kept) */
+    const R rsc = lsm ? R(0.0) : R(1.0);
+    /* ---- this lane's stage: everything that does not depend on ds_k ---- */
+    R sk[6], sn[6];
+    load_state(k, I, sk);
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) sn[i] = ws.it(k, I, F_S + i);
+    const R v = sk[3];
+    const R delta = ws.it(k, I, F_U + 0), acc = ws.it(k, I, F_U + 1);
+    LinR L;
+    linearise(sk, delta, acc, sn, L);
+    R gk[GK_N], gf0 = ws.it(k, J, F_GK + GK_N + 0), gf1 = ws.it(k, J, F_GK + GK_N + 1);
+    MPC_UNROLL
+    for (int j = 0; j < GK_N; j++) gk[j] = ws.it(k, J, F_GK + j);
+    const R vdt = v * dt, Apv = delta * dtLf, Bp = v * dtLf;
+    const R xs[4] = {sn[2], sn[3], delta, acc};
+    const R lo[4] = {yl, vl, dl, al}, hi[4] = {yu, vu, du, au};
+    R isl[4], isu[4], zl[4], zu[4], izl[4], izu[4];
+    MPC_UNROLL
+    for (int b = 0; b < 4; b++) {
+      isl[b] = frcp1(xs[b] - lo[b]); isu[b] = frcp1(hi[b] - xs[b]);
+      zl[b] = ws.it(k, I, F_ZL + b); zu[b] = ws.it(k, I, F_ZU + b);
+      izl[b] = frcp1(zl[b]); izu[b] = frcp1(zu[b]);
+    }
+    const R delprev_k = k > 0 ? (R)ws.it(k - 1, I, F_U + 0) : R(0.0);
+    const R xinf_k = mpc_max(mpc_max(mpc_abs(sn[0]), mpc_abs(sn[1])), mpc_max(mpc_abs(sn[3]), mpc_abs(sn[4])));
+    /* ---- the start of the recursion (wave-uniform: forward()'s own preamble) ---- */
+    R d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0, ddprev = 0;
+    R rmax = R(0.0), rzmax = R(0.0);
+    dphi = R(0.0); dxinf = R(0.0); xinf = R(0.0);
+#if MPC_S0_VARIABLE
+    d2 = rsc * (st[2] - p0); d3 = rsc * (st[3] - v0k);
+    if (d2 != R(0.0) || d3 != R(0.0)) {
+      const R islp = frcp1(p0 - yl), isup = frcp1(yu - p0), islv = frcp1(v0k - vl), isuv = frcp1(vu - v0k);
+      rmax = mpc_max(mpc_max(-d2 * islp, d2 * isup), mpc_max(-d3 * islv, d3 * isuv));
+      dphi = mu * ((isup - islp) * d2 + (isuv - islv) * d3);
+      dxinf = mpc_max(mpc_abs(d2), mpc_abs(d3));
+    }
+    const R s0d2 = d2, s0d3 = d3;
+#endif
+    R dn[D_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* ---- the recursion: stage t is lane t's turn ---- */
+    for (int t = 0; t < M; ++t) {
+      R dd = gf0, da = gf1;
+      dd += gk[0] * d0 + gk[1] * d1 + gk[2] * d2 + gk[3] * d3 + gk[4] * d5 + gk[5] * ddprev;
+      da += gk[6] * d0 + gk[7] * d1 + gk[8] * d2 + gk[9] * d3 + gk[10] * d5 + gk[11] * ddprev;
+      const R n0 = d0 - vdt * L.sp * d2 + dt * L.cp * d3 - rsc * L.c[0];
+      const R n1 = d1 + vdt * L.cp * d2 + dt * L.sp * d3 - rsc * L.c[1];
+      const R n2 = d2 + Apv * d3 + Bp * dd - rsc * L.c[2];
+      const R n3 = d3 + dt * da - rsc * L.c[3];
+      const R n4 = L.fp * d0 - d1 + dt * L.se * d3 + vdt * L.ce * d5 - rsc * L.c[4];
+      const R n5 = -L.g1 * d0 + d2 + Apv * d3 + Bp * dd - rsc * L.c[5];
+      const R dx[4] = {n2, n3, dd, da};
+      R rm = rmax, rz = rzmax, dp = dphi;
+      MPC_UNROLL
+      for (int b = 0; b < 4; b++) {
+        rm = mpc_max(rm, mpc_max(-dx[b] * isl[b], dx[b] * isu[b]));
+        const R dzl = mu * isl[b] - zl[b] - zl[b] * isl[b] * dx[b];
+        const R dzu = mu * isu[b] - zu[b] + zu[b] * isu[b] * dx[b];
+        rz = mpc_max(rz, mpc_max(-dzl * izl[b], -dzu * izu[b]));
+        dp += mu * (isu[b] - isl[b]) * dx[b];
+      }
+      R g = R(2.0) * wc * sn[4] * n4 + R(2.0) * we * sn[5] * n5 + R(2.0) * wv * (sn[3] - vref) * n3 + R(2.0) * wd * delta * dd;
+      if (t > 0) g += R(2.0) * wdd * (delta - delprev_k) * (dd - ddprev);
+      dp += df * g;
+      const R dxs = mpc_max(dxinf, mpc_max(mpc_max(mpc_max(mpc_abs(n0), mpc_abs(n1)), mpc_max(mpc_abs(n2), mpc_abs(n3))),
+                                        mpc_max(mpc_max(mpc_abs(n4), mpc_abs(n5)), mpc_max(mpc_abs(dd), mpc_abs(da)))));
+      const R xis = mpc_max(xinf, xinf_k);
+      if (wlane == t) { dn[0] = n0; dn[1] = n1; dn[2] = n2; dn[3] = n3; dn[4] = n4; dn[5] = n5; dn[6] = dd; dn[7] = da; }
+      /* lane t's results are the state of the recursion */
+      d0 = wave_bcast(n0, t); d1 = wave_bcast(n1, t); d2 = wave_bcast(n2, t); d3 = wave_bcast(n3, t); d5 = wave_bcast(n5, t);
+      ddprev = wave_bcast(dd, t);
+      rmax = wave_bcast(rm, t); rzmax = wave_bcast(rz, t); dphi = wave_bcast(dp, t); dxinf = wave_bcast(dxs, t); xinf = wave_bcast(xis, t);
+    }
+    if (mine) ws.template store_run<F_D, D_N>(k, 0, dn);
+#if MPC_S0_VARIABLE
+    if (s0_rows && !lsm) {
+      const R xs0[2] = {p0, v0k}, lo0[2] = {yl, vl}, hi0[2] = {yu, vu}, dx0[2] = {s0d2, s0d3};
+      MPC_UNROLL
+      for (int b = 0; b < 2; b++) {
+        const R isl0 = frcp1(xs0[b] - lo0[b]), isu0 = frcp1(hi0[b] - xs0[b]);
+        const R zl0 = s0_z(I, b, 0), zu0 = s0_z(I, b, 1);
+        const R dzl = mu * isl0 - zl0 - zl0 * isl0 * dx0[b];
+        const R dzu = mu * isu0 - zu0 + zu0 * isu0 * dx0[b];
+        rzmax = mpc_max(rzmax, mpc_max(-dzl * frcp1(zl0), -dzu * frcp1(zu0)));
+      }
+    }
+#endif
+    amax = (rmax > tau) ? tau / rmax : R(1.0);
+    az = (rzmax > tau) ? tau / rzmax : R(1.0);
+  }
+
   MPC_HD void forward() {
+    if constexpr (WAVE) { forward_wave(); return; }
     const int I = it(cur), J = it(1 - cur);
     R d0 = 0, d1 = 0, d2 = 0, d3 = 0, d5 = 0; /* ds_k: x,y,psi,v,(c),e */
     R ddprev = 0, delprev = 0;                 /* d(delta_{k-1}), delta_{k-1} */
@@ -1374,8 +1488,181 @@ struct Solver {
         del_t = n_del_t; acc_t = n_acc_t; zdl_t = n_zdl; zdu_t = n_zdu; zal_t = n_zal; zau_t = n_zau;
         del_o = n_del_o; acc_o = n_acc_o; ddk = n_ddk; lx = lo0; ly = lo1; lp = lo2; lc = lo4; le = lo5;
     };
-    MPC_STAGE_LOOP
-    for (int k = M; k >= 1; --k) step_k(std::false_type(), k);
+    if constexpr (WAVE) {
+      /* One instance per wavefront: lane r does step k = r + 1 (record r, transition k) for all stages at once.  What runs through
+       * the lanes in order is only what the sequential sweep carries from step to step: the costate lam+ (six multiply-add rows
+       * per stage) and, in a second turn, the sums of the evaluation in the order the sequential sweep adds them. */
+      const bool mine = wlane < M;
+      const int r = mine ? wlane : M - 1, k = r + 1;
+      const bool last = k == M;
+      const int rn = last ? r : r + 1;                /* record k (clamped at the terminal stage, where it is not used) */
+      R s_o[6], ds[6], lo_[6], snc[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { s_o[i] = ws.it(r, I, F_S + i); ds[i] = ws.it(r, 0, F_D + D_S + i); lo_[i] = ws.it(r, I, F_LAM + i); snc[i] = ws.it(rn, I, F_S + i); }
+      const R n_del_o = ws.it(r, I, F_U + 0), n_acc_o = ws.it(r, I, F_U + 1);
+      const R ddel = ws.it(r, 0, F_D + D_U + 0), dacc = ws.it(r, 0, F_D + D_U + 1);
+      R zlc[4], zuc[4];
+      MPC_UNROLL
+      for (int b = 0; b < 4; b++) { zlc[b] = ws.it(r, I, F_ZL + b); zuc[b] = ws.it(r, I, F_ZU + b); }
+      const R del_k = ws.it(rn, I, F_U + 0), acc_k = ws.it(rn, I, F_U + 1), ddk_k = ws.it(rn, 0, F_D + D_U + 0);
+      const R lxk = ws.it(rn, I, F_LAM + 0), lyk = ws.it(rn, I, F_LAM + 1), lpk = ws.it(rn, I, F_LAM + 2), lck = ws.it(rn, I, F_LAM + 4), lek = ws.it(rn, I, F_LAM + 5);
+      /* ---- costate: this stage's coefficients, then the recursion ---- */
+      R Lm[6] = {0, 0, 0, 0, 0, 0};
+      if (with_costate) {
+        R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+        state_terms(s_o[2], s_o[3], s_o[4], s_o[5], zlc[0], zuc[0], zlc[1], zuc[1], Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+        const R v = s_o[3];
+        LinR L;
+        linearise(s_o, del_k, acc_k, snc, L);
+        const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+        const R vdt = v * dt, Apv = del_k * dtLf;
+        const R Hxx = -lck * fpp + lek * h3, Hpsi2 = (lxk * cp + lyk * sp) * vdt, Hpv = (lxk * sp - lyk * cp) * dt;
+        const R Hee2 = lck * vdt * se, Hev = -lck * dt * ce, Hvd = -(lpk + lek) * dtLf;
+        for (int t = M; t >= 1; --t) {
+          R n0, n1, n2, n3, n4, n5;
+          if (last) {
+            n0 = -(hxy * ds[0]);
+            n1 = -(hxy * ds[1]);
+            n2 = -(gp + (Hpp + dw) * ds[2]);
+            n3 = -(gv + (Hvv + dw) * ds[3]);
+            n4 = -(gc + (Hcc + dw) * ds[4]);
+            n5 = -(ge + (Hee + dw) * ds[5]);
+          } else {
+            const R L25 = L2 + L5;
+            n0 = L0 + fp * L4 - g1 * L5 - (Hxx + hxy) * ds[0];
+            n1 = L1 - L4 - hxy * ds[1];
+            n2 = -vdt * sp * L0 + vdt * cp * L1 + L25 - gp - (Hpp + dw + Hpsi2) * ds[2] - Hpv * ds[3];
+            n3 = dt * cp * L0 + dt * sp * L1 + Apv * L25 + L3 + dt * se * L4 - gv - Hpv * ds[2] -
+                 (Hvv + dw) * ds[3] - Hev * ds[5] - Hvd * ddk_k;
+            n4 = -gc - (Hcc + dw) * ds[4];
+            n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * ds[5] - Hev * ds[3];
+          }
+          if (wlane == t - 1) { Lm[0] = n0; Lm[1] = n1; Lm[2] = n2; Lm[3] = n3; Lm[4] = n4; Lm[5] = n5; }
+          L0 = wave_bcast(n0, t - 1); L1 = wave_bcast(n1, t - 1); L2 = wave_bcast(n2, t - 1);
+          L3 = wave_bcast(n3, t - 1); L4 = wave_bcast(n4, t - 1); L5 = wave_bcast(n5, t - 1);
+        }
+      }
+      R dl[6] = {0, 0, 0, 0, 0, 0};
+      R lmax_k = R(0.0);
+      if (with_costate) {
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) dl[i] = Lm[i] - lo_[i];
+        lmax_k = mpc_max(mpc_max(mpc_max(mpc_abs(dl[0]), mpc_abs(dl[1])), mpc_max(mpc_abs(dl[2]), mpc_abs(dl[3]))), mpc_max(mpc_abs(dl[4]), mpc_abs(dl[5])));
+      }
+      /* ---- trial record r ---- */
+      R lam_t[6], s_t[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { lam_t[i] = lo_[i] + alpha_l * dl[i]; s_t[i] = s_o[i] + alpha * ds[i]; }
+      const R n_del_t = n_del_o + alpha * ddel, n_acc_t = n_acc_o + alpha * dacc;
+      R rec[IT_SZ] = {};
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { rec[F_S + i] = s_t[i]; rec[F_LAM + i] = lam_t[i]; }
+      rec[F_U] = n_del_t; rec[F_U + 1] = n_acc_t;
+      const R xo[4] = {s_o[2], s_o[3], n_del_o, n_acc_o};
+      const R xn[4] = {s_t[2], s_t[3], n_del_t, n_acc_t};
+      const R dxb[4] = {ds[2], ds[3], ddel, dacc};
+      const R lo[4] = {yl, vl, this->dl, al}, hi[4] = {yu, vu, du, au};
+      R zln[4], zun[4], sl_[4], su_[4], prod = R(1.0);
+      bool bad = false;
+      MPC_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const R islo = frcp1(xo[b] - lo[b]), isuo = frcp1(hi[b] - xo[b]);
+        const R dzl = mu * islo - zlc[b] - zlc[b] * islo * dxb[b];
+        const R dzu = mu * isuo - zuc[b] + zuc[b] * isuo * dxb[b];
+        const R sl = xn[b] - lo[b], su = hi[b] - xn[b];
+        if (!(sl > R(0.0)) || !(su > R(0.0))) bad = true;
+        const R isl = frcp1(sl), isu = frcp1(su);
+        R a = zlc[b] + alpha_z * dzl, c = zuc[b] + alpha_z * dzu;
+        a = mpc_max(mpc_min(a, ksm * isl), ksi * isl);
+        c = mpc_max(mpc_min(c, ksm * isu), ksi * isu);
+        zln[b] = a; zun[b] = c; sl_[b] = sl; su_[b] = su;
+        prod *= sl * su;
+        rec[F_ZL + b] = a; rec[F_ZU + b] = c;
+      }
+      if (mine) {
+        ws.template store_run<F_S, F_ZL - F_S>(r, J, rec + F_S);
+        ws.template store_run<F_ZL, 8>(r, J, rec + F_ZL);
+      }
+      const R lprod = flog(prod);
+      /* ---- transition k at the trial point (the neighbours' trial records are in LDS now) ---- */
+      R cT[6] = {0, 0, 0, 0, 0, 0}, ddl = 0, dinf_u = 0, dinf_s = 0;
+      if (!last) {
+        R snt[6], lnt[6];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) { snt[i] = ws.it(rn, J, F_S + i); lnt[i] = ws.it(rn, J, F_LAM + i); }
+        const R dlt = ws.it(rn, J, F_U + 0), act = ws.it(rn, J, F_U + 1);
+        const R zdl = ws.it(rn, J, F_ZL + 2), zdu = ws.it(rn, J, F_ZU + 2), zal = ws.it(rn, J, F_ZL + 3), zau = ws.it(rn, J, F_ZU + 3);
+        const R dnx = (k + 1 < M) ? (R)ws.it(rn + 1 < M ? rn + 1 : rn, J, F_U + 0) : R(0.0);
+        LinR Lt;
+        linearise(s_t, dlt, act, snt, Lt);
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) cT[i] = Lt.c[i];
+        ddl = dlt - n_del_t;
+        const R ddn = (k + 1 < M) ? dnx - dlt : R(0.0);
+        const R v = s_t[3], vdt = v * dt, Apv = dlt * dtLf, Bp = v * dtLf;
+        const R l25 = lnt[2] + lnt[5];
+        const R rd = df * (R(2.0) * wd * dlt + R(2.0) * wdd * ddl - R(2.0) * wdd * ddn) - Bp * l25 - zdl + zdu;
+        const R ra = -dt * lnt[3] - zal + zau;
+        dinf_u = mpc_max(mpc_abs(rd), mpc_abs(ra));
+        const R r0 = lam_t[0] - (lnt[0] + Lt.fp * lnt[4] - Lt.g1 * lnt[5]);
+        const R r1 = lam_t[1] - (lnt[1] - lnt[4]);
+        const R r2 = lam_t[2] - (-vdt * Lt.sp * lnt[0] + vdt * Lt.cp * lnt[1] + l25) - zln[0] + zun[0];
+        const R r3 = df * R(2.0) * (wv * (s_t[3] - vref)) + lam_t[3] -
+                          (dt * Lt.cp * lnt[0] + dt * Lt.sp * lnt[1] + Apv * l25 + lnt[3] + dt * Lt.se * lnt[4]) - zln[1] + zun[1];
+        const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
+        const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5] - vdt * Lt.ce * lnt[4];
+        dinf_s = mpc_max(mpc_max(mpc_abs(r0), mpc_abs(r1)), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5))));
+      } else {
+        const R r2 = lam_t[2] - zln[0] + zun[0];
+        const R r3 = df * R(2.0) * wv * (s_t[3] - vref) + lam_t[3] - zln[1] + zun[1];
+        const R r4 = df * R(2.0) * wc * s_t[4] + lam_t[4];
+        const R r5 = df * R(2.0) * we * s_t[5] + lam_t[5];
+        dinf_s = mpc_max(mpc_max(mpc_abs(lam_t[0]), mpc_abs(lam_t[1])), mpc_max(mpc_max(mpc_abs(r2), mpc_abs(r3)), mpc_max(mpc_abs(r4), mpc_abs(r5))));
+      }
+      /* ---- the sums, in the order of the sequential sweep ---- */
+      for (int t = M; t >= 1; --t) {
+        R e_ls = Ev.lsum, e_zs = Ev.zsum, e_L = Ev.L, e_f = Ev.f, e_th = Ev.theta, e_ci = Ev.cinf, e_di = Ev.dinf, e_mn = Ev.cmin, e_mx = Ev.cmax, e_lm = lmax;
+        e_lm = mpc_max(e_lm, lmax_k);
+        MPC_UNROLL
+        for (int i = 0; i < 6; i += 2) e_ls += mpc_abs(lam_t[i]) + mpc_abs(lam_t[i + 1]);
+        MPC_UNROLL
+        for (int b = 0; b < 4; b++) {
+          e_zs += zln[b] + zun[b];
+          const R pl = sl_[b] * zln[b], pu = su_[b] * zun[b];
+          e_mn = mpc_min(e_mn, mpc_min(pl, pu)); e_mx = mpc_max(e_mx, mpc_max(pl, pu));
+        }
+        e_L += lprod;
+        const R dv = s_t[3] - vref;
+        e_f += wc * s_t[4] * s_t[4] + we * s_t[5] * s_t[5] + wv * dv * dv + wd * n_del_t * n_del_t;
+        if (!last) {
+          MPC_UNROLL
+          for (int i = 0; i < 6; i++) { e_th += mpc_abs(cT[i]); e_ci = mpc_max(e_ci, mpc_abs(cT[i])); }
+          e_f += wdd * ddl * ddl;
+          e_di = mpc_max(e_di, dinf_u);
+        }
+        e_di = mpc_max(e_di, dinf_s);
+        Ev.lsum = wave_bcast(e_ls, t - 1); Ev.zsum = wave_bcast(e_zs, t - 1); Ev.L = wave_bcast(e_L, t - 1); Ev.f = wave_bcast(e_f, t - 1);
+        Ev.theta = wave_bcast(e_th, t - 1); Ev.cinf = wave_bcast(e_ci, t - 1); Ev.dinf = wave_bcast(e_di, t - 1);
+        Ev.cmin = wave_bcast(e_mn, t - 1); Ev.cmax = wave_bcast(e_mx, t - 1); lmax = wave_bcast(e_lm, t - 1);
+      }
+      Ev.du0 = wave_bcast(mpc_max(mpc_abs(ddel), mpc_abs(dacc)), 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (__builtin_amdgcn_ballot_w64(mine && bad) != 0ull) Ev.ok = false;
+#else
+      if (bad) Ev.ok = false;
+#endif
+      /* ---- what the step of k = 1 hands to the last one ---- */
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { sn_o[i] = ws.it(0, I, F_S + i); sn_t[i] = ws.it(0, J, F_S + i); ln_t[i] = ws.it(0, J, F_LAM + i); }
+      del_nx = M >= 2 ? (R)ws.it(1, J, F_U + 0) : R(0.0);
+      del_t = ws.it(0, J, F_U + 0); acc_t = ws.it(0, J, F_U + 1);
+      zdl_t = ws.it(0, J, F_ZL + 2); zdu_t = ws.it(0, J, F_ZU + 2); zal_t = ws.it(0, J, F_ZL + 3); zau_t = ws.it(0, J, F_ZU + 3);
+      del_o = ws.it(0, I, F_U + 0); acc_o = ws.it(0, I, F_U + 1); ddk = ws.it(0, 0, F_D + D_U + 0);
+      lx = ws.it(0, I, F_LAM + 0); ly = ws.it(0, I, F_LAM + 1); lp = ws.it(0, I, F_LAM + 2); lc = ws.it(0, I, F_LAM + 4); le = ws.it(0, I, F_LAM + 5);
+    } else {
+      MPC_STAGE_LOOP
+      for (int k = M; k >= 1; --k) step_k(std::false_type(), k);
+    }
     step_k(std::true_type(), 0);
     if (!(Ev.theta == Ev.theta) || !(Ev.f == Ev.f) || !(Ev.L == Ev.L) || !(Ev.dinf == Ev.dinf)) Ev.ok = false;
     return Ev;

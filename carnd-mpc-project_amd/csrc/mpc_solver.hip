@@ -811,6 +811,45 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
   if (iters) iters[i] = S.iters;
 }
 
+/* ONE INSTANCE PER WAVEFRONT (launches of a few instances: one MPC::solve() per telemetry message is the reference's own use).
+ * The instance's N-step variables live in the workgroup's LDS ([stage][field], 3.7 KB at N = 10 in fp64); every lane of the wave
+ * runs the solver's state machine on them -- the decisions are wave-uniform -- and the sweeps share their work between the
+ * lanes (mpc::Solver<WS, R, true>: see forward_wave / costate_trial_wave in mpc_core.h). */
+template <class R>
+__global__ __launch_bounds__(kBlock, 1) void mpc_solve_wave_kernel(
+    const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
+    const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
+    const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+  extern __shared__ double smem[];
+  using WS = mpc::LdsWorkspace<R, 1>;
+  using SV = mpc::Solver<WS, R, true>;
+  const int64_t i = blockIdx.x;
+  if (i >= B) return;
+  WS ws;
+  ws.base = (typename WS::lreal *)smem;
+  ws.lane = 0;                       /* every lane addresses the one instance */
+  SV S(P, ws);
+  S.wlane = threadIdx.x;
+  R st[6], cf[MPC_NCOEF], w[MPC_NW];
+#pragma unroll
+  for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < MPC_NCOEF; q++) cf[q] = coeffs[q * ld + i];
+#pragma unroll
+  for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)P.weights[q];
+  int r = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, true);
+  if (r == MPC_STATUS_SUCCESS) r = S.solve();
+  if (threadIdx.x == 0) {
+    R *o = out + i;
+    R *t = traj ? traj + i : nullptr;
+    const int64_t l = ldo;
+    S.unpack([o, l](int q) -> R & { return o[q * l]; }, [t, l](int q) -> R & { return t[q * l]; }, traj != nullptr, yaw_lo[i], yaw_hi[i]);
+    status[i] = r;
+    if (iters) iters[i] = S.iters;
+  }
+}
+
 /* MPC::run pre-processing, one instance per lane (mpc_run_core.h).  rows of `pre`: state 0..5, coeffs 6..10,
  * yaw_lo 11, yaw_hi 12, max_yaw_change 13, target_speed 14 */
 template <bool TELEMETRY>
@@ -975,6 +1014,7 @@ struct MpcHandle {
   int64_t ws_stride = 0;   /* reals (double, or float for MPC_PRECISION_F32) per wavefront tile of the workspace */
   bool staging = true;
   int lds_lanes = 0;       /* instances per workgroup of the LDS-resident kernel (0: N too large for it, or MPC_LDS=0) */
+  int64_t wave_max_batch = 0;   /* launches up to this size run one instance per wavefront (mpc_solve_wave_kernel); 0: never */
   int64_t lds_max_batch = 0;   /* launches up to this size take the LDS-resident kernel: lds_lanes x number of CUs */
   bool mixed = false;      /* two phases per solve: fp32 up to MpcParams.mixed_switch_mu, then fp64 to tol (f32_finish on an F32 handle,
                             * f64_f32_start on an F64 handle) */
@@ -1243,6 +1283,7 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     if (fn) MPC_CREATE_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
     if (const char *e = getenv("MPC_LDS_MAX_BATCH")) h->lds_max_batch = atoll(e);
   }
+  if (const char *e = getenv("MPC_WAVE_MAX_BATCH")) h->wave_max_batch = atoll(e);
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -1894,7 +1935,8 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   const int64_t waves_full = (B + kBlock - 1) / kBlock;
   int64_t waves = (waves_full + h->inst_per_lane - 1) / h->inst_per_lane;
   if (waves < 1) waves = 1;
-  bool defer = may_defer && h->params.tail_cut != 0 && B >= h->tail_min_batch && (h->mixed || !(h->lds_lanes > 0 && B <= h->lds_max_batch));
+  bool defer = may_defer && h->params.tail_cut != 0 && B >= h->tail_min_batch && (h->mixed || !(h->lds_lanes > 0 && B <= h->lds_max_batch)) &&
+               !(h->wave_max_batch > 0 && B <= h->wave_max_batch);
   MpcHandle::BatchRec *rec = nullptr;
   { const int rc = batch_rec(h, h->batch_seq, &rec); if (rc != MPC_OK) return rc; }
   rec->id = 0;                                      /* (valid once the launch has been issued) */
@@ -1945,7 +1987,8 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     ++h->n_deferred;
     return tail_pump(h, false);
   };
-  if (h->mixed) {
+  const bool wave_path = h->wave_max_batch > 0 && B <= h->wave_max_batch;
+  if (h->mixed && !wave_path) {
     MpcPhase TT;
     memset(&TT, 0, sizeof(TT));
     tail_fields(TT);
@@ -1961,6 +2004,19 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
     if (!h->ws2) MPC_HIP_CHECK(hipMalloc((void **)&h->ws2, ws_bytes));
     if (!h->d_park) MPC_HIP_CHECK(hipMalloc((void **)&h->d_park, sizeof(double) * 2 * kParkRows * h->io_stride));
     if (!h->d_list) MPC_HIP_CHECK(hipMalloc((void **)&h->d_list, sizeof(int32_t) * 4 * h->io_stride));
+  }
+  if (h->wave_max_batch > 0 && B <= h->wave_max_batch) {
+    --h->counter_seq;                              /* (this path uses no counters: the block stays clean for the next call) */
+    MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
+    const size_t lds = (size_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4, h->params.initial_state_rows != 0) * sizeof(R);
+    hipLaunchKernelGGL((mpc_solve_wave_kernel<R>), dim3((unsigned)B), dim3(kBlock), lds, s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
+                       weights, out, traj, status, iters ? iters : h->d_iters);
+    MPC_HIP_CHECK(hipGetLastError());
+    MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    { const int rt = tail_done(); if (rt != MPC_OK) return rt; }
+    if (with_stats) stats_later(iters ? iters : h->d_iters);
+    return MPC_OK;
   }
   if (h->lds_lanes > 0 && B <= h->lds_max_batch) {
     --h->counter_seq;                              /* (this path uses no counters: the block stays clean for the next call) */
