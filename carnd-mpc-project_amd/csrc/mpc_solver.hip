@@ -1159,12 +1159,9 @@ static void set_cuts(MpcHandle *h, const MpcParams *p) {
  * (MPC_F32_START_AUTO; the default is 0 = off) from the horizon at which the workspace of a full device no longer lives in the
  * Infinity Cache */
 static bool wants_mixed(const MpcParams *p, int64_t max_batch) {
+  (void)max_batch;
   if (p->precision == MPC_PRECISION_F32) return p->f32_finish != 0;
-  /* AUTO: long horizons (the workspace of a full device is in HBM proper: the fp32 record's bytes pay), and handles of one
-   * wavefront at most -- a lone wave is bound by the instructions it issues, and the fp32 solver's light math issues fewer:
-   * one MPC::solve() (B = 1, N = 10) 0.53 instead of 0.68 ms.  Not in between: at 4 096 instances per launch the second
-   * launch costs more than the fp32 phase saves (13.1 against 17.8 M solves/s). */
-  return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && (p->N >= MPC_F32_START_AUTO_N || max_batch <= MPC_F32_START_AUTO_MAX_BATCH));
+  return p->f64_f32_start == 1 || (p->f64_f32_start == MPC_F32_START_AUTO && p->N >= MPC_F32_START_AUTO_N);
 }
 
 static int validate_params(const MpcParams *p) {
@@ -1283,7 +1280,15 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     if (fn) MPC_CREATE_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
     if (const char *e = getenv("MPC_LDS_MAX_BATCH")) h->lds_max_batch = atoll(e);
   }
+  /* Launches of at most one wavefront's worth of instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the lane
+   * kernel would put them all into one wave, which is bound by the instructions it issues -- one MPC::solve() 0.68 ms; with the
+   * sweeps shared between the lanes 0.37 ms, bitwise the same results.  (A launch of 1 024 instances: 0.69 against 1.22 ms;
+   * from ~2 000 on the lane kernel is ahead, and for many small launches in flight it always is: MPC_WAVE_MAX_BATCH moves the
+   * limit, 0 switches the kernel off.)  Not for an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle: those ask for
+   * the two-launch solve. */
+  h->wave_max_batch = 64;
   if (const char *e = getenv("MPC_WAVE_MAX_BATCH")) h->wave_max_batch = atoll(e);
+  if (p->f64_f32_start == MPC_F32_START_ON || (p->precision == MPC_PRECISION_F32 && p->f32_finish != 0)) h->wave_max_batch = 0;
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };

@@ -65,7 +65,6 @@ enum {
 enum { MPC_BRANCH_FROZEN = 0, MPC_BRANCH_LIVE = 1 };
 enum { MPC_F32_START_OFF = 0, MPC_F32_START_ON = 1, MPC_F32_START_AUTO = 2 };   /* MpcParams.f64_f32_start */
 #define MPC_F32_START_AUTO_N 15
-#define MPC_F32_START_AUTO_MAX_BATCH 64   /* ... and handles created for at most one wavefront of instances (single solves) */
 enum { MPC_PRECISION_F64 = 0, MPC_PRECISION_F32 = 1 };
 enum { MPC_TAIL_OFF = 0, MPC_TAIL_AUTO = -1 };   /* MpcParams.tail_cut */
 enum { MPC_LANE_COMPACT_AUTO = -1 };             /* MpcParams.lane_compact */
@@ -153,9 +152,8 @@ typedef struct MpcParams {
    * so is one the fp64 phase cannot finish from the fp32 iterate: on hard instances fp32 iterates lead into other
    * local minima than fp64 ones.  With that rule the CPU build gives the single-phase solve's status and point (1e-7)
    * on every instance of SURVEY's unfiltered populations (65 536 at N = 10, 32 768 at N = 25).
-   * Default MPC_F32_START_AUTO: long horizons start on the fp32 record, and so do handles created for at most
-   * MPC_F32_START_AUTO_MAX_BATCH instances (a lone wave is bound by the instructions it issues, of which the fp32 solver's
-   * light math needs fewer: one solve at N = 10 takes 0.53 instead of 0.68 ms).  Measured in round 4 with the tail slices on the
+   * Default MPC_F32_START_AUTO: long horizons start on the fp32 record.  (Launches of at most 64 instances do not go through
+   * the two-launch solve at all: they run one instance per wavefront, every iteration in fp64 -- DESIGN.md section 6d.)  Measured in round 4 with the tail slices on the
    * tail stream's high priority (windows of 600 batches): N = 25, SURVEY's population 9.8-10.0 M against 7.1-8.8 M solves/s,
    * the filtered generator 11.0-11.9 against 7.6 M; 0 status differences and at most 4.1e-8 rad on the first steering
    * angle over the 32 768 instances of SURVEY's N = 25 population (profiles/r04_f32start_vs_plain.jsonl).  Not for short

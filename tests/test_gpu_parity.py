@@ -123,6 +123,46 @@ def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torc
     assert 0.2 < rp["iters"].mean() - r["iters"].mean() < 1.0
 
 
+@pytest.mark.parametrize("case", ["headline", "N25", "weights", "rows", "f32pure", "N3"])
+def test_one_instance_per_wavefront_is_bitwise_the_lane_kernel(pkg, golden_dir, waypoints, torch_dev, case, monkeypatch):
+    """mpc_solve_wave_kernel (launches of at most 64 instances; MPC_WAVE_MAX_BATCH moves the limit): one instance per wavefront, its
+    N-step variables in LDS, the forward and costate/trial sweeps shared between the lanes -- stage k's model, gains and slacks by
+    lane k, the recursions through the lanes in order with the sequential sweeps' own statements.  Status, iteration count, outputs
+    and trajectories are BITWISE those of the lane-per-instance kernel, on SURVEY's population (hard instances included)."""
+    import torch
+    over = dict(N=25, dt=0.05) if case == "N25" else (dict(N=3, dt=0.2) if case == "N3" else {})
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json" if case == "N25" else "config-fast.json"), **over)
+    params.f64_f32_start = 0
+    if case == "rows":
+        params.initial_state_rows = 1
+    f32 = case == "f32pure"
+    if f32:
+        params.precision = pkg.PRECISION_F32; params.f32_finish = 0
+    B = 192
+    b = pkg.scenarios.lake_track_batch(B, params, waypoints, stream=3, filtered="survey")
+    w = pkg.scenarios.weight_sweep(B, params, seed=5, velocity_weights=(0.0, 1.0, 100.0)) if case == "weights" else None
+    tdt = torch.float32 if f32 else torch.float64
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev, dtype=tdt)
+    ins = [t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"])]
+    res = {}
+    for mode, limit in (("lane", "0"), ("wave", "1000000")):
+        monkeypatch.setenv("MPC_WAVE_MAX_BATCH", limit)
+        with pkg.BatchedMPC(params, B, device=0) as mpc:
+            r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
+            torch.cuda.synchronize()
+            res[mode] = {k: v.cpu().numpy() for k, v in r.items()}
+    a, c = res["lane"], res["wave"]
+    assert (a["status"] == 0).sum() >= B - 8
+    for k in ("status", "iters", "out", "traj"):
+        assert np.array_equal(a[k], c[k], equal_nan=True), (case, k, np.where(a["status"] != c["status"])[0][:5])
+    # and the default: a launch of up to 64 instances takes the wave kernel by itself (same bits again)
+    monkeypatch.delenv("MPC_WAVE_MAX_BATCH")
+    with pkg.BatchedMPC(params, 64, device=0) as mpc:
+        r = mpc.solve_torch(*[x[..., :64].contiguous() for x in ins], weights=t(w[:, :64]) if w is not None else None, want_traj=True)
+        torch.cuda.synchronize()
+    assert np.array_equal(r["out"].cpu().numpy(), a["out"][:, :64], equal_nan=True) and np.array_equal(r["iters"].cpu().numpy(), a["iters"][:64])
+
+
 def test_initial_state_rows_on_the_device(pkg, host_twin, golden_dir, waypoints, torch_dev):
     """MpcParams.initial_state_rows = 1 on the device: the iteration counts of the CPU build of the same solver (which are the
     oracle's on all but 1-2 % of a batch, tests/test_host_twin.py), the oracle's statuses and points -- also in the mixed-precision
