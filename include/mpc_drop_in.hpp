@@ -116,12 +116,10 @@ struct Config {
   /* solver controls that have no counterpart among the reference's statics */
   inline static int maxIterations = 200;
   inline static double tolerance = 1e-8;
-  /* One MPC::solve() per telemetry message is a single serial chain on the device: a lone wave is bound by the instructions it
-   * issues, and the fp32 solver's light math issues fewer.  With the early iterations on the fp32 record
-   * (MpcParams.f64_f32_start; every solve still finished by the fp64 solver to `tolerance` and the polish) a B = 1 solve takes
-   * 0.53 ms instead of 0.68 ms -- unless its hand-over is not clean (hard instances), in which case the solve starts again in
-   * fp64 and takes longer than the all-fp64 one.  2 (default) = the library's own choice, MPC_F32_START_AUTO: handles of one
-   * wavefront at most, like this class's, and long horizons start on the fp32 record; 0 = every iteration in fp64; 1 = always. */
+  /* MpcParams.f64_f32_start of the handles this class creates: 2 (default) = the library's own choice, MPC_F32_START_AUTO (long
+   * horizons start on the fp32 record; every solve still finished by the fp64 solver to `tolerance` and the polish); 0 = every
+   * iteration in fp64; 1 = always the two-launch solve.  One MPC::solve() per telemetry message runs one instance per wavefront
+   * whatever the horizon (0.37 ms at N = 10) unless this is 1. */
   inline static int fp32Start = 2;
 
   /* Config::load(fileName), Config.cpp:31-87 (parsing and unit conversion live behind the C ABI) */
