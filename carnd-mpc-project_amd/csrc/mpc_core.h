@@ -350,6 +350,11 @@ inline double wave_bcast(double x, int) { return x; }
 inline float wave_bcast(float x, int) { return x; }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool wave_bcast_flag(bool x, int lane) { return __builtin_amdgcn_readlane(x ? 1 : 0, lane) != 0; }
+#else
+inline bool wave_bcast_flag(bool x, int) { return x; }
+#endif
 MPC_HD double frcp1(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
@@ -772,7 +777,231 @@ struct Solver {
   /* Returns false when some R~_k is not positive definite (wrong        */
   /* inertia): the caller raises the regularisation dw and repeats.      */
   /* ------------------------------------------------------------------ */
+  /* The Riccati sweep with one instance per wavefront: lane k prepares stage k (inputs, model, reciprocal slacks, control and state
+   * terms); the value-function recursion runs through the lanes in descending order -- the stage algebra of backward(), statement
+   * for statement, on the value function the lane before broadcast (29 numbers) -- and lane k stores stage k's gains. */
+  MPC_HD bool backward_wave(R dw) {
+    const int I = it(cur), J = it(1 - cur);         /* J: where the gains go */
+    /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1; only the lower triangle of the symmetric
+     * matrices is ever written or read (PM/MX pick it), so the other half never occupies registers */
+    R Pm[6][6], p[6], Pcc, pc;
+#define PM(i, j) Pm[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
+#define MX(i, j) Mx[(i) >= (j) ? (i) : (j)][(i) >= (j) ? (j) : (i)]
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) {
+      p[i] = 0;
+      MPC_UNROLL
+      for (int j = 0; j < 6; j++) Pm[i][j] = 0;
+    }
+    const R rsc = lsm ? R(0.0) : -R(1.0);             /* constraint right-hand side: -c, or 0 for the LS system */
+    const R hxy = (lsm ? R(1.0) : R(0.0)) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
+    /* Staging: record j of the iterate (the fields of stage j) sits in buffer (M-1-j)&1.  Stage k needs
+     * (u_k, lam_{k+1}, duals of u_k) from record k -- moved to registers one iteration earlier -- and
+     * (s_k, delta_{k-1}, duals of s_k) from record k-1; record k-2 is requested meanwhile. */
+    ws.stage_drain();
+    ws.stage_fetch_it(0, M - 1, I);
+    ws.template stage_wait<0>();
+    R sn[6];                                    /* s_{k+1} */
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
+    {
+      R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+      state_terms(sn[2], sn[3], sn[4], sn[5], ws.sit(0, M - 1, I, F_ZL + 0), ws.sit(0, M - 1, I, F_ZU + 0),
+                  ws.sit(0, M - 1, I, F_ZL + 1), ws.sit(0, M - 1, I, F_ZU + 1), Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+      Pm[0][0] = hxy; Pm[1][1] = hxy; Pm[2][2] = Hpp + dw; Pm[3][3] = Hvv + dw; Pm[4][4] = Hee + dw;
+      Pcc = Hcc + dw; p[2] = gp; p[3] = gv; p[4] = ge; pc = gc;
+    }
+    /* ---- this lane's stage: inputs, model, reciprocal slacks, the control terms and the state terms of the value function ---- */
+    const int k = wlane < M ? wlane : M - 1;      /* (the lanes behind the last stage repeat it; nothing of theirs is kept) */
+    MPC_UNROLL
+    for (int i = 0; i < 6; i++) sn[i] = ws.it(k, I, F_S + i);
+    const R delta = ws.it(k, I, F_U + 0), acc = ws.it(k, I, F_U + 1);
+    const R lx = ws.it(k, I, F_LAM + 0), ly = ws.it(k, I, F_LAM + 1), lp = ws.it(k, I, F_LAM + 2);
+    const R lc = ws.it(k, I, F_LAM + 4), le = ws.it(k, I, F_LAM + 5);
+    const R zld = ws.it(k, I, F_ZL + 2), zud = ws.it(k, I, F_ZU + 2), zla = ws.it(k, I, F_ZL + 3), zua = ws.it(k, I, F_ZU + 3);
+    R sk[6];
+    R zlp = 0, zup = 0, zlv = 0, zuv = 0, delprev = 0;
+    if (k > 0) {
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sk[i] = ws.it(k - 1, I, F_S + i);
+      zlp = ws.it(k - 1, I, F_ZL + 0); zup = ws.it(k - 1, I, F_ZU + 0);
+      zlv = ws.it(k - 1, I, F_ZL + 1); zuv = ws.it(k - 1, I, F_ZU + 1);
+      delprev = ws.it(k - 1, I, F_U + 0);
+    } else {
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) sk[i] = st[i];
+#if MPC_S0_VARIABLE
+      sk[2] = p0; sk[3] = v0k;
+#endif
+    }
+    const R v = sk[3];
+    LinR L;
+    linearise(sk, delta, acc, sn, L);
+    const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1, h3 = L.h3, fpp = L.fpp;
+    const R r0 = rsc * L.c[0], r1 = rsc * L.c[1], r2 = rsc * L.c[2], r3 = rsc * L.c[3], rc = rsc * L.c[4], r4 = rsc * L.c[5];
+    const R vdt = v * dt;
+    const R Axp = -vdt * sp, Axv = dt * cp, Ayp = vdt * cp, Ayv = dt * sp, Apv = delta * dtLf;
+    const R Acx = fp, Acv = dt * se, Ace = vdt * ce, Aex = -g1, Bp = v * dtLf;
+    /* the stage's own control terms */
+    const R isld = frcp1(delta - dl), isud = frcp1(du - delta), isla = frcp1(acc - al), isua = frcp1(au - acc);
+    R ddl = 0, Hdd = 0;
+    if (k >= 1 && !lsm) { ddl = delta - delprev; Hdd = df * R(2.0) * wdd; }   /* LS start: all delta are 0 */
+    const R mub = lsm ? R(0.0) : mu;
+    const R gdel = df * R(2.0) * wd * delta + Hdd * ddl + mub * (isud - isld);
+    const R gacc = mub * (isua - isla);
+    /* control Hessian diagonal: cost + barrier, or the identity of the LS system */
+    const R Sgd = lsm ? R(1.0) : df * R(2.0) * wd + zld * isld + zud * isud, Sga = lsm ? R(1.0) : zla * isla + zua * isua;
+    /* ---- value function of stage k ---- */
+    R Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc;
+    state_terms(sk[2], v, sk[4], sk[5], zlp, zup, zlv, zuv, Hpp, Hvv, Hee, Hcc, gp, gv, ge, gc);
+    /* ---- the recursion: stage t is lane t's turn; its value function is the state the next lane starts from ---- */
+    bool ok_all = true;
+    for (int tk = M - 1; tk >= 0; --tk) {
+      bool ok_k = true;
+      /* t = p + P r (the d component of r is zero) */
+      R t[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++)
+        t[i] = p[i] + PM(i, 0) * r0 + PM(i, 1) * r1 + PM(i, 2) * r2 + PM(i, 3) * r3 + PM(i, 4) * r4;
+      const R tc = pc + Pcc * rc;
+      /* G^T applied to a (6-vector, c-scalar): outputs for inputs x,y,psi,v,e,delta,a */
+#define MPC_GT(w, wcs, o)                                                         \
+  do {                                                                            \
+    const R w24_ = (w)[2] + (w)[4];                                          \
+    (o)[0] = (w)[0] + Aex * (w)[4] + Acx * (wcs);                                 \
+    (o)[1] = (w)[1] - (wcs);                                                      \
+    (o)[2] = Axp * (w)[0] + Ayp * (w)[1] + w24_;                                  \
+    (o)[3] = Axv * (w)[0] + Ayv * (w)[1] + Apv * w24_ + (w)[3] + Acv * (wcs);     \
+    (o)[4] = Ace * (wcs);                                                         \
+    (o)[5] = Bp * w24_ + (w)[5];                                                  \
+    (o)[6] = dt * (w)[3];                                                         \
+  } while (0)
+      R qt[7];
+      MPC_GT(t, tc, qt);
+      const R rt_d = qt[5] + gdel, rt_a = qt[6] + gacc;
+      R w5[6], w6[6];
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) { w5[i] = Bp * (PM(i, 2) + PM(i, 4)) + PM(i, 5); w6[i] = dt * PM(i, 3); }
+      if (tk == 0) {
+        /* the feed-forward of u_0, and the feedback on the only components of ds_0 that can be non-zero: psi_0, v_0 */
+        R o5[7], o6[7];
+        MPC_GT(w5, R(0.0), o5);
+        MPC_GT(w6, R(0.0), o6);
+        const R Rdd = o5[5] + Sgd + dw;
+        const R Rda = o6[5];
+        const R Raa = o6[6] + Sga + dw;
+        const R det = Rdd * Raa - Rda * Rda;
+        if (!(Rdd > R(0.0)) || !(det > R(0.0))) ok_k = false;
+        const R idet = frcp1(det);
+        const R i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
+        const R Sd2 = o5[2], Sd3 = o5[3] - (lp + le) * dtLf, Sa2 = o6[2], Sa3 = o6[3];   /* S~ columns of psi_0, v_0 (with the Lagrangian Hessian's d-v term) */
+        R gn[GAIN_SZ] = {};
+        gn[2] = -(i11 * Sd2 + i12 * Sa2); gn[3] = -(i11 * Sd3 + i12 * Sa3);
+        gn[6 + 2] = -(i12 * Sd2 + i22 * Sa2); gn[6 + 3] = -(i12 * Sd3 + i22 * Sa3);
+        gn[GK_N] = -(Raa * rt_d - Rda * rt_a) * idet; gn[GK_N + 1] = -(-Rda * rt_d + Rdd * rt_a) * idet;
+        if (wlane == 0) ws.template store_run<F_GK, GAIN_SZ>(0, J, gn);
+        ok_all = wave_bcast_flag(ok_k, 0);
+        break;
+      }
+      /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
+      R Mx[7][7];
+      {
+        R w[6], o[7];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) w[i] = PM(i, 0) + Aex * PM(i, 4);
+        MPC_GT(w, Pcc * Acx, o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][0] = o[i];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) w[i] = PM(i, 1);
+        MPC_GT(w, -Pcc, o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][1] = o[i];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) w[i] = Axp * PM(i, 0) + Ayp * PM(i, 1) + PM(i, 2) + PM(i, 4);
+        MPC_GT(w, R(0.0), o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][2] = o[i];
+        MPC_UNROLL
+        for (int i = 0; i < 6; i++) w[i] = Axv * PM(i, 0) + Ayv * PM(i, 1) + Apv * (PM(i, 2) + PM(i, 4)) + PM(i, 3);
+        MPC_GT(w, Pcc * Acv, o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][3] = o[i];
+        {
+          /* input e only feeds cte+: column = G^T (0, Pcc*Ace) */
+          const R wcs = Pcc * Ace;
+          Mx[0][4] = Acx * wcs; Mx[1][4] = -wcs; Mx[2][4] = R(0.0); Mx[3][4] = Acv * wcs; Mx[4][4] = Ace * wcs;
+          Mx[5][4] = R(0.0); Mx[6][4] = R(0.0);
+        }
+        MPC_GT(w5, R(0.0), o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][5] = o[i];
+        MPC_GT(w6, R(0.0), o);
+        MPC_UNROLL
+        for (int i = 0; i < 7; i++) Mx[i][6] = o[i];
+      }
+      /* ---- add the Lagrangian Hessian of stage k: -lam_{k+1}^T d2F ---- */
+      Mx[0][0] += -lc * fpp + le * h3;
+      Mx[2][2] += (lx * cp + ly * sp) * vdt;
+      Mx[3][2] += (lx * sp - ly * cp) * dt;
+      Mx[4][4] += lc * vdt * se;
+      Mx[4][3] += -lc * dt * ce;
+      Mx[5][3] += -(lp + le) * dtLf;
+      /* control terms */
+      const R Rdd = Mx[5][5] + Hdd + Sgd + dw;
+      const R Rda = Mx[6][5];
+      const R Raa = Mx[6][6] + Sga + dw;
+      const R det = Rdd * Raa - Rda * Rda;
+      if (!(Rdd > R(0.0)) || !(det > R(0.0))) ok_k = false;
+      const R idet = frcp1(det);
+      const R i11 = Raa * idet, i12 = -Rda * idet, i22 = Rdd * idet;
+      /* S~ (2 x 6 over x,y,psi,v,e,d) */
+      R Sd[6], Sa[6], Kd[6], Ka[6];
+      MPC_UNROLL
+      for (int j = 0; j < 5; j++) { Sd[j] = Mx[5][j]; Sa[j] = Mx[6][j]; }
+      Sd[5] = -Hdd; Sa[5] = R(0.0);
+      MPC_UNROLL
+      for (int j = 0; j < 6; j++) {
+        Kd[j] = -(i11 * Sd[j] + i12 * Sa[j]);
+        Ka[j] = -(i12 * Sd[j] + i22 * Sa[j]);
+      }
+      const R kfd = -(i11 * rt_d + i12 * rt_a), kfa = -(i12 * rt_d + i22 * rt_a);
+      R gn[GAIN_SZ] = {};
+      MPC_UNROLL
+      for (int j = 0; j < 6; j++) { gn[j] = Kd[j]; gn[6 + j] = Ka[j]; }
+      gn[GK_N] = kfd; gn[GK_N + 1] = kfa;
+      if (wlane == tk) ws.template store_run<F_GK, GAIN_SZ>(k, J, gn);
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) {
+        MPC_UNROLL
+        for (int j = 0; j <= i; j++) {
+          R q = (i < 5) ? Mx[i][j] : ((j == 5) ? Hdd : R(0.0));
+          q += Sd[i] * Kd[j] + Sa[i] * Ka[j];
+          Pm[i][j] = q;
+        }
+        p[i] = ((i < 5) ? qt[i] : -Hdd * ddl) + Sd[i] * kfd + Sa[i] * kfa;
+      }
+      Pm[0][0] += hxy; Pm[1][1] += hxy; Pm[2][2] += Hpp + dw; Pm[3][3] += Hvv + dw; Pm[4][4] += Hee + dw;
+      p[2] += gp; p[3] += gv; p[4] += ge;
+      Pcc = Hcc + dw; pc = gc;
+      /* lane tk's verdict and value function are the wave's */
+      if (!wave_bcast_flag(ok_k, tk)) { ok_all = false; break; }
+      MPC_UNROLL
+      for (int i = 0; i < 6; i++) {
+        MPC_UNROLL
+        for (int j = 0; j <= i; j++) Pm[i][j] = wave_bcast(Pm[i][j], tk);
+        p[i] = wave_bcast(p[i], tk);
+      }
+      Pcc = wave_bcast(Pcc, tk); pc = wave_bcast(pc, tk);
+    }
+#undef MPC_GT
+#undef PM
+#undef MX
+    return ok_all;
+  }
+
   MPC_HD bool backward(R dw) {
+    if constexpr (WAVE) return backward_wave(dw);
     const int I = it(cur), J = it(1 - cur);         /* J: where the gains go */
     /* value function of (x,y,psi,v,e,d) [+ c] at stage k+1; only the lower triangle of the symmetric
      * matrices is ever written or read (PM/MX pick it), so the other half never occupies registers */

@@ -814,7 +814,7 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
 /* ONE INSTANCE PER WAVEFRONT (launches of a few instances: one MPC::solve() per telemetry message is the reference's own use).
  * The instance's N-step variables live in the workgroup's LDS ([stage][field], 3.7 KB at N = 10 in fp64); every lane of the wave
  * runs the solver's state machine on them -- the decisions are wave-uniform -- and the sweeps share their work between the
- * lanes (mpc::Solver<WS, R, true>: see forward_wave / costate_trial_wave in mpc_core.h). */
+ * lanes (mpc::Solver<WS, R, true>: backward_wave, forward_wave and the wave form of costate_trial in mpc_core.h). */
 template <class R>
 __global__ __launch_bounds__(kBlock, 1) void mpc_solve_wave_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
@@ -1282,8 +1282,8 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   }
   /* Launches of at most one wavefront's worth of instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the lane
    * kernel would put them all into one wave, which is bound by the instructions it issues -- one MPC::solve() 0.68 ms; with the
-   * sweeps shared between the lanes 0.37 ms, bitwise the same results.  (A launch of 1 024 instances: 0.69 against 1.22 ms;
-   * from ~2 000 on the lane kernel is ahead, and for many small launches in flight it always is: MPC_WAVE_MAX_BATCH moves the
+   * sweeps shared between the lanes 0.30 ms, bitwise the same results.  (A launch of 1 024 instances: 0.54 against 1.22 ms;
+   * from ~4 000 on the lane kernel is ahead, and for many small launches in flight it always is: MPC_WAVE_MAX_BATCH moves the
    * limit, 0 switches the kernel off.)  Not for an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle: those ask for
    * the two-launch solve. */
   h->wave_max_batch = 64;

@@ -119,7 +119,7 @@ struct Config {
   /* MpcParams.f64_f32_start of the handles this class creates: 2 (default) = the library's own choice, MPC_F32_START_AUTO (long
    * horizons start on the fp32 record; every solve still finished by the fp64 solver to `tolerance` and the polish); 0 = every
    * iteration in fp64; 1 = always the two-launch solve.  One MPC::solve() per telemetry message runs one instance per wavefront
-   * whatever the horizon (0.37 ms at N = 10) unless this is 1. */
+   * whatever the horizon (0.30 ms at N = 10) unless this is 1. */
   inline static int fp32Start = 2;
 
   /* Config::load(fileName), Config.cpp:31-87 (parsing and unit conversion live behind the C ABI) */

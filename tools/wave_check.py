@@ -19,7 +19,7 @@ for config, over, B in (("config-fast.json", {}, 256), ("config-stable.json", di
     res = {}
     for mode in ("lane", "wave"):
         if mode == "wave": os.environ["MPC_WAVE_MAX_BATCH"] = "1024"
-        else: os.environ.pop("MPC_WAVE_MAX_BATCH", None)
+        else: os.environ["MPC_WAVE_MAX_BATCH"] = "0"
         with pkg.BatchedMPC(p, B, device=0) as mpc:
             r = mpc.solve_torch(*ins, want_traj=True); torch.cuda.synchronize()
             res[mode] = {k: v.cpu().numpy() for k, v in r.items()}
