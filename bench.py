@@ -900,7 +900,7 @@ def main():
                                 "matches_device_path_bitwise": host_ok,
                                 "b1_latency_ms_median": 1e3 * float(np.median(lat[10:])), "b1_latency_ms_min": 1e3 * float(np.min(lat[10:])),
                                 "b1_kernel_ms": k1, "b1_iterations": int(r1["iters"][0]),
-                                "b1_note": "one MPC::solve() per telemetry message is what the reference does (mpc_main.cpp:167); includes the ctypes call"}
+                                "b1_note": "one MPC::solve() per telemetry message is what the reference does (mpc_main.cpp:167); includes the ctypes call; launches of at most 64 instances run one instance per wavefront (mpc_solve_wave_kernel)"}
     # IPOPT's own stopping rule (polish = 0) on the same batch, once: what the device returns then (compared with the oracle below)
     out_p0 = None
     if world == 1 and stub is None and not args.no_cpu_baseline and not f32:
