@@ -45,7 +45,7 @@ class MpcParams(C.Structure):
         ("lane_compact", C.c_int32), ("f32_phase_refill", C.c_int32), ("acceptable_iter", C.c_int32),
         ("dual_inf_tol", C.c_double), ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double),
         ("acceptable_tol", C.c_double), ("acceptable_dual_inf_tol", C.c_double),
-        ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double), ("initial_state_rows", C.c_int32), ("reserved_i", C.c_int32),
+        ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double), ("initial_state_rows", C.c_int32), ("wave_max_batch", C.c_int32),
     ]
 
     def copy(self):

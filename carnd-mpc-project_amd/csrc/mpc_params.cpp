@@ -107,7 +107,7 @@ extern "C" int mpc_params_default(MpcParams *p) {
   p->lane_compact = MPC_LANE_COMPACT_AUTO; p->f32_phase_refill = 0;
   /* IPOPT 3.12 defaults of the termination tests the reference's option string leaves alone (MPC.cpp:160-179) */
   p->acceptable_iter = 15; p->dual_inf_tol = 1.0; p->constr_viol_tol = 1e-4; p->compl_inf_tol = 1e-4;
-  p->initial_state_rows = 0; p->reserved_i = 0;
+  p->initial_state_rows = 0; p->wave_max_batch = 0;
   p->acceptable_tol = 1e-6; p->acceptable_dual_inf_tol = 1e10; p->acceptable_constr_viol_tol = 1e-2; p->acceptable_compl_inf_tol = 1e-2;
   return MPC_OK;
 }

@@ -1139,6 +1139,12 @@ struct MpcHandle {
 
 /* the cut schedule of the multi-phase solve: MpcParams.pass_cut, pass_cut_next[0..2] (a zero ends the list), overridden
  * by MPC_PASS_CUT=a[,b[,c[,d]]] in the environment */
+static void set_wave_limit(MpcHandle *h, const MpcParams *p) {
+  h->wave_max_batch = p->wave_max_batch == 0 ? 64 : (p->wave_max_batch < 0 ? 0 : p->wave_max_batch);
+  if (const char *e = getenv("MPC_WAVE_MAX_BATCH")) h->wave_max_batch = atoll(e);      /* (A/B measurements) */
+  if (p->f64_f32_start == MPC_F32_START_ON || (p->precision == MPC_PRECISION_F32 && p->f32_finish != 0)) h->wave_max_batch = 0;
+}
+
 static void set_cuts(MpcHandle *h, const MpcParams *p) {
   h->n_cuts = 0;
   const int32_t given[kMaxCuts] = {p->pass_cut, p->pass_cut_next[0], p->pass_cut_next[1], p->pass_cut_next[2]};
@@ -1283,12 +1289,10 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
   /* Launches of at most one wavefront's worth of instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the lane
    * kernel would put them all into one wave, which is bound by the instructions it issues -- one MPC::solve() 0.68 ms; with the
    * sweeps shared between the lanes 0.30 ms, bitwise the same results.  (A launch of 1 024 instances: 0.54 against 1.22 ms;
-   * from ~4 000 on the lane kernel is ahead, and for many small launches in flight it always is: MPC_WAVE_MAX_BATCH moves the
-   * limit, 0 switches the kernel off.)  Not for an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle: those ask for
+   * from ~4 000 on the lane kernel is ahead, and for many small launches in flight it always is: MpcParams.wave_max_batch moves
+   * the limit or switches the kernel off.)  Not for an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle: those ask for
    * the two-launch solve. */
-  h->wave_max_batch = 64;
-  if (const char *e = getenv("MPC_WAVE_MAX_BATCH")) h->wave_max_batch = atoll(e);
-  if (p->f64_f32_start == MPC_F32_START_ON || (p->precision == MPC_PRECISION_F32 && p->f32_finish != 0)) h->wave_max_batch = 0;
+  set_wave_limit(h, p);
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));
   auto fail = [&](hipError_t e, const char *what) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); mpc_destroy(h); return MPC_ERR_HIP; };
@@ -1362,6 +1366,7 @@ extern "C" int mpc_set_params(MpcHandle *h, const MpcParams *p) {
   }
   h->params = *p;
   set_cuts(h, p);
+  set_wave_limit(h, p);
   if (!h->compact_env) h->compact_gap = p->lane_compact >= 0 ? p->lane_compact : (p->N >= 15 ? 1 : 2);
   if (!h->promote_env) h->promote_buffer = p->f32_phase_refill != 0;
   return MPC_OK;

@@ -202,7 +202,13 @@ typedef struct MpcParams {
    * step's rounding) at ~4 % of the rate (ten more fields per instance and sweep).  0 (default): not carried; the barrier
    * parameter then comes down one iteration early on a few per cent of the instances.  Same solution either way. */
   int32_t initial_state_rows;
-  int32_t reserved_i;
+  /* Launches of at most this many instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the
+   * instance's N-step variables in LDS, its stages shared between the lanes of the wave, bitwise the results of the
+   * lane-per-instance kernel.  A latency mapping: one MPC::solve() 0.30 instead of 0.68 ms, a launch of 1 024 instances 0.54
+   * instead of 1.22 ms, level at ~4 000; it spends a SIMD per instance, so many small launches in flight are better off with the
+   * lane kernel.  0 (default) = 64 (what the lane kernel would put into a single wave); < 0 = never.  Not used by an explicit
+   * f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle (those ask for the two-launch solve). */
+  int32_t wave_max_batch;
 } MpcParams;
 
 typedef struct MpcHandle MpcHandle;

@@ -54,7 +54,7 @@ def test_params_from_json_match_oracle_config(pkg, golden_dir, name):
     assert list(p.steer_speeds)[:p.n_steer_speeds] == list(c.steer_speeds)[:c.n_steer_speeds]
     assert list(p.yaw_change_speeds)[:p.n_yaw_change_speeds] == list(c.yaw_change_speeds)[:c.n_yaw_change_speeds]
     assert p.branch_mode == 0 and p.precision == 0 and p.tol == 1e-8
-    assert p.lane_compact == -1 and p.tail_cut == 0 and p.f32_finish == 1 and p.f64_f32_start == 2 and p.initial_state_rows == 0 and p.f32_phase_refill == 0
+    assert p.lane_compact == -1 and p.tail_cut == 0 and p.f32_finish == 1 and p.f64_f32_start == 2 and p.initial_state_rows == 0 and p.wave_max_batch == 0 and p.f32_phase_refill == 0
 
 
 def test_params_errors(pkg, tmp_path):

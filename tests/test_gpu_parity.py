@@ -155,8 +155,19 @@ def test_one_instance_per_wavefront_is_bitwise_the_lane_kernel(pkg, golden_dir, 
     assert (a["status"] == 0).sum() >= B - 8
     for k in ("status", "iters", "out", "traj"):
         assert np.array_equal(a[k], c[k], equal_nan=True), (case, k, np.where(a["status"] != c["status"])[0][:5])
-    # and the default: a launch of up to 64 instances takes the wave kernel by itself (same bits again)
+    # the same through MpcParams.wave_max_batch, and changed on a live handle
     monkeypatch.delenv("MPC_WAVE_MAX_BATCH")
+    q = params.copy(); q.wave_max_batch = 192
+    with pkg.BatchedMPC(q, B, device=0) as mpc:
+        r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["out"].cpu().numpy(), a["out"], equal_nan=True) and np.array_equal(r["status"].cpu().numpy(), a["status"])
+        q.wave_max_batch = -1
+        mpc.set_params(q)
+        r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["out"].cpu().numpy(), a["out"], equal_nan=True)
+    # and the default: a launch of up to 64 instances takes the wave kernel by itself (same bits again)
     with pkg.BatchedMPC(params, 64, device=0) as mpc:
         r = mpc.solve_torch(*[x[..., :64].contiguous() for x in ins], weights=t(w[:, :64]) if w is not None else None, want_traj=True)
         torch.cuda.synchronize()
