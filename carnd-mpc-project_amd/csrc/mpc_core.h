@@ -338,23 +338,34 @@ MPC_HD double frcp(double x) {
   return 1.0 / x;
 #endif
 }
-/* the value lane `lane` (wave-uniform) holds, in every lane: v_readlane_b32 per 32 bits (one instance per wavefront) */
+/* Cross-lane reads of the one-instance-per-LPI-lanes kernels.  LPI = 64 (one instance per wavefront): the value lane `lane`
+ * (wave-uniform) holds, in every lane -- v_readlane_b32 per 32 bits.  LPI < 64 (several instances per wavefront, each on LPI
+ * neighbouring lanes): the value lane `base + lane` holds, `base` being the first lane of the reader's own group --
+ * ds_bpermute_b32 per 32 bits (the instances of a wave may be in different phases: a wave-uniform source does not exist). */
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ double wave_bcast(double x, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+template <int LPI> __device__ __forceinline__ int wave_bcast_i(int x, int lane, int base) {
+  if constexpr (LPI >= 64) return __builtin_amdgcn_readlane(x, lane);
+  else return __builtin_amdgcn_ds_bpermute((base + lane) << 2, x);
+}
+template <int LPI> __device__ __forceinline__ double wave_bcast(double x, int lane, int base) {
+  const int lo = wave_bcast_i<LPI>(__double2loint(x), lane, base), hi = wave_bcast_i<LPI>(__double2hiint(x), lane, base);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float wave_bcast(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+template <int LPI> __device__ __forceinline__ float wave_bcast(float x, int lane, int base) { return __int_as_float(wave_bcast_i<LPI>(__float_as_int(x), lane, base)); }
+template <int LPI> __device__ __forceinline__ bool wave_bcast_flag(bool x, int lane, int base) { return wave_bcast_i<LPI>(x ? 1 : 0, lane, base) != 0; }
+/* does any lane of the reader's group say so? */
+template <int LPI> __device__ __forceinline__ bool wave_group_any(bool x, int base) {
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(x);
+  if constexpr (LPI >= 64) return b != 0ull;
+  else return ((b >> base) & ((1ull << LPI) - 1ull)) != 0ull;
+}
 #else
-inline double wave_bcast(double x, int) { return x; }
-inline float wave_bcast(float x, int) { return x; }
+template <int LPI> inline double wave_bcast(double x, int, int) { return x; }
+template <int LPI> inline float wave_bcast(float x, int, int) { return x; }
+template <int LPI> inline bool wave_bcast_flag(bool x, int, int) { return x; }
+template <int LPI> inline bool wave_group_any(bool x, int) { return x; }
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ bool wave_bcast_flag(bool x, int lane) { return __builtin_amdgcn_readlane(x ? 1 : 0, lane) != 0; }
-#else
-inline bool wave_bcast_flag(bool x, int) { return x; }
-#endif
 MPC_HD double frcp1(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
@@ -623,9 +634,10 @@ struct Lin {
   R c[6];
 };
 
-/* WAVE = true: one instance per wavefront (mpc_solve_wave_kernel): every lane runs this state machine on the same instance,
- * `wlane` is the lane's number, and the sweeps that have a wave form share their stages between the lanes */
-template <class WS, class R, bool WAVE = false>
+/* WAVE = LPI > 0: one instance per LPI neighbouring lanes of a wavefront (mpc_solve_wave_kernel; 64 = the whole wave): every lane
+ * of the group runs this state machine on the same instance, `wlane` is the lane's number in its group, `wbase` the group's first
+ * lane, and the sweeps share their stages between the lanes of the group */
+template <class WS, class R, int WAVE = 0>
 struct Solver {
   using F = Fields<R>;
   using IC = IpmConst<R>;
@@ -638,7 +650,7 @@ struct Solver {
   static constexpr int ST_BACKWARD = F::ST_BACKWARD, ST_FORWARD = F::ST_FORWARD, ST_TRIAL = F::ST_TRIAL;
   const MpcParams &P;
   WS ws;
-  int wlane = 0;
+  int wlane = 0, wbase = 0;
   /* instance data */
   R st[6], coef[MPC_NCOEF], yl, yu;
   R wc, we, wv, wd, wdd, vref, cost0;
@@ -900,7 +912,7 @@ struct Solver {
         gn[6 + 2] = -(i12 * Sd2 + i22 * Sa2); gn[6 + 3] = -(i12 * Sd3 + i22 * Sa3);
         gn[GK_N] = -(Raa * rt_d - Rda * rt_a) * idet; gn[GK_N + 1] = -(-Rda * rt_d + Rdd * rt_a) * idet;
         if (wlane == 0) ws.template store_run<F_GK, GAIN_SZ>(0, J, gn);
-        ok_all = wave_bcast_flag(ok_k, 0);
+        ok_all = wave_bcast_flag<WAVE>(ok_k, 0, wbase);
         break;
       }
       /* ---- W = P G (columns for inputs x,y,psi,v,e,delta,a) and Mx = G^T W ---- */
@@ -985,14 +997,14 @@ struct Solver {
       p[2] += gp; p[3] += gv; p[4] += ge;
       Pcc = Hcc + dw; pc = gc;
       /* lane tk's verdict and value function are the wave's */
-      if (!wave_bcast_flag(ok_k, tk)) { ok_all = false; break; }
+      if (!wave_bcast_flag<WAVE>(ok_k, tk, wbase)) { ok_all = false; break; }
       MPC_UNROLL
       for (int i = 0; i < 6; i++) {
         MPC_UNROLL
-        for (int j = 0; j <= i; j++) Pm[i][j] = wave_bcast(Pm[i][j], tk);
-        p[i] = wave_bcast(p[i], tk);
+        for (int j = 0; j <= i; j++) Pm[i][j] = wave_bcast<WAVE>(Pm[i][j], tk, wbase);
+        p[i] = wave_bcast<WAVE>(p[i], tk, wbase);
       }
-      Pcc = wave_bcast(Pcc, tk); pc = wave_bcast(pc, tk);
+      Pcc = wave_bcast<WAVE>(Pcc, tk, wbase); pc = wave_bcast<WAVE>(pc, tk, wbase);
     }
 #undef MPC_GT
 #undef PM
@@ -1305,9 +1317,9 @@ struct Solver {
       const R xis = mpc_max(xinf, xinf_k);
       if (wlane == t) { dn[0] = n0; dn[1] = n1; dn[2] = n2; dn[3] = n3; dn[4] = n4; dn[5] = n5; dn[6] = dd; dn[7] = da; }
       /* lane t's results are the state of the recursion */
-      d0 = wave_bcast(n0, t); d1 = wave_bcast(n1, t); d2 = wave_bcast(n2, t); d3 = wave_bcast(n3, t); d5 = wave_bcast(n5, t);
-      ddprev = wave_bcast(dd, t);
-      rmax = wave_bcast(rm, t); rzmax = wave_bcast(rz, t); dphi = wave_bcast(dp, t); dxinf = wave_bcast(dxs, t); xinf = wave_bcast(xis, t);
+      d0 = wave_bcast<WAVE>(n0, t, wbase); d1 = wave_bcast<WAVE>(n1, t, wbase); d2 = wave_bcast<WAVE>(n2, t, wbase); d3 = wave_bcast<WAVE>(n3, t, wbase); d5 = wave_bcast<WAVE>(n5, t, wbase);
+      ddprev = wave_bcast<WAVE>(dd, t, wbase);
+      rmax = wave_bcast<WAVE>(rm, t, wbase); rzmax = wave_bcast<WAVE>(rz, t, wbase); dphi = wave_bcast<WAVE>(dp, t, wbase); dxinf = wave_bcast<WAVE>(dxs, t, wbase); xinf = wave_bcast<WAVE>(xis, t, wbase);
     }
     if (mine) ws.template store_run<F_D, D_N>(k, 0, dn);
 #if MPC_S0_VARIABLE
@@ -1767,8 +1779,8 @@ struct Solver {
             n5 = vdt * ce * L4 - ge - (Hee + dw + Hee2) * ds[5] - Hev * ds[3];
           }
           if (wlane == t - 1) { Lm[0] = n0; Lm[1] = n1; Lm[2] = n2; Lm[3] = n3; Lm[4] = n4; Lm[5] = n5; }
-          L0 = wave_bcast(n0, t - 1); L1 = wave_bcast(n1, t - 1); L2 = wave_bcast(n2, t - 1);
-          L3 = wave_bcast(n3, t - 1); L4 = wave_bcast(n4, t - 1); L5 = wave_bcast(n5, t - 1);
+          L0 = wave_bcast<WAVE>(n0, t - 1, wbase); L1 = wave_bcast<WAVE>(n1, t - 1, wbase); L2 = wave_bcast<WAVE>(n2, t - 1, wbase);
+          L3 = wave_bcast<WAVE>(n3, t - 1, wbase); L4 = wave_bcast<WAVE>(n4, t - 1, wbase); L5 = wave_bcast<WAVE>(n5, t - 1, wbase);
         }
       }
       R dl[6] = {0, 0, 0, 0, 0, 0};
@@ -1870,16 +1882,12 @@ struct Solver {
           e_di = mpc_max(e_di, dinf_u);
         }
         e_di = mpc_max(e_di, dinf_s);
-        Ev.lsum = wave_bcast(e_ls, t - 1); Ev.zsum = wave_bcast(e_zs, t - 1); Ev.L = wave_bcast(e_L, t - 1); Ev.f = wave_bcast(e_f, t - 1);
-        Ev.theta = wave_bcast(e_th, t - 1); Ev.cinf = wave_bcast(e_ci, t - 1); Ev.dinf = wave_bcast(e_di, t - 1);
-        Ev.cmin = wave_bcast(e_mn, t - 1); Ev.cmax = wave_bcast(e_mx, t - 1); lmax = wave_bcast(e_lm, t - 1);
+        Ev.lsum = wave_bcast<WAVE>(e_ls, t - 1, wbase); Ev.zsum = wave_bcast<WAVE>(e_zs, t - 1, wbase); Ev.L = wave_bcast<WAVE>(e_L, t - 1, wbase); Ev.f = wave_bcast<WAVE>(e_f, t - 1, wbase);
+        Ev.theta = wave_bcast<WAVE>(e_th, t - 1, wbase); Ev.cinf = wave_bcast<WAVE>(e_ci, t - 1, wbase); Ev.dinf = wave_bcast<WAVE>(e_di, t - 1, wbase);
+        Ev.cmin = wave_bcast<WAVE>(e_mn, t - 1, wbase); Ev.cmax = wave_bcast<WAVE>(e_mx, t - 1, wbase); lmax = wave_bcast<WAVE>(e_lm, t - 1, wbase);
       }
-      Ev.du0 = wave_bcast(mpc_max(mpc_abs(ddel), mpc_abs(dacc)), 0);
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (__builtin_amdgcn_ballot_w64(mine && bad) != 0ull) Ev.ok = false;
-#else
-      if (bad) Ev.ok = false;
-#endif
+      Ev.du0 = wave_bcast<WAVE>(mpc_max(mpc_abs(ddel), mpc_abs(dacc)), 0, wbase);
+      if (wave_group_any<WAVE>(mine && bad, wbase)) Ev.ok = false;
       /* ---- what the step of k = 1 hands to the last one ---- */
       MPC_UNROLL
       for (int i = 0; i < 6; i++) { sn_o[i] = ws.it(0, I, F_S + i); sn_t[i] = ws.it(0, J, F_S + i); ln_t[i] = ws.it(0, J, F_LAM + i); }

@@ -815,22 +815,24 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
  * The instance's N-step variables live in the workgroup's LDS ([stage][field], 3.7 KB at N = 10 in fp64); every lane of the wave
  * runs the solver's state machine on them -- the decisions are wave-uniform -- and the sweeps share their work between the
  * lanes (mpc::Solver<WS, R, true>: backward_wave, forward_wave and the wave form of costate_trial in mpc_core.h). */
-template <class R>
+template <class R, int LPI>
 __global__ __launch_bounds__(kBlock, 1) void mpc_solve_wave_kernel(
     const MpcParams P, const int64_t B, const int64_t ld, const int64_t ldo, const R *__restrict__ state,
     const R *__restrict__ coeffs, const R *__restrict__ yaw_lo, const R *__restrict__ yaw_hi,
     const R *__restrict__ weights, R *__restrict__ out, R *__restrict__ traj,
     int32_t *__restrict__ status, int32_t *__restrict__ iters) {
   extern __shared__ double smem[];
-  using WS = mpc::LdsWorkspace<R, 1>;
-  using SV = mpc::Solver<WS, R, true>;
-  const int64_t i = blockIdx.x;
-  if (i >= B) return;
+  constexpr int G = 64 / LPI;                       /* instances per wavefront: each on LPI neighbouring lanes */
+  using WS = mpc::LdsWorkspace<R, G>;
+  using SV = mpc::Solver<WS, R, LPI>;
+  const int group = threadIdx.x / LPI;
+  const int64_t i = (int64_t)blockIdx.x * G + group;
+  if (i >= B) return;                               /* (whole groups: nobody reads their lanes) */
   WS ws;
   ws.base = (typename WS::lreal *)smem;
-  ws.lane = 0;                       /* every lane addresses the one instance */
+  ws.lane = group;                                  /* every lane of the group addresses the group's instance */
   SV S(P, ws);
-  S.wlane = threadIdx.x;
+  S.wlane = threadIdx.x % LPI; S.wbase = group * LPI;
   R st[6], cf[MPC_NCOEF], w[MPC_NW];
 #pragma unroll
   for (int q = 0; q < 6; q++) st[q] = state[q * ld + i];
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_wave_kernel(
   for (int q = 0; q < MPC_NW; q++) w[q] = weights ? weights[q * ld + i] : (R)P.weights[q];
   int r = S.setup(st, cf, yaw_lo[i], yaw_hi[i], w, true);
   if (r == MPC_STATUS_SUCCESS) r = S.solve();
-  if (threadIdx.x == 0) {
+  if (S.wlane == 0) {
     R *o = out + i;
     R *t = traj ? traj + i : nullptr;
     const int64_t l = ldo;
@@ -1015,6 +1017,7 @@ struct MpcHandle {
   bool staging = true;
   int lds_lanes = 0;       /* instances per workgroup of the LDS-resident kernel (0: N too large for it, or MPC_LDS=0) */
   int64_t wave_max_batch = 0;   /* launches up to this size run one instance per wavefront (mpc_solve_wave_kernel); 0: never */
+  int64_t wave_whole_max = 16;  /* ... and up to this size an instance gets the whole wave (v_readlane) even where 16 lanes would do */
   int64_t lds_max_batch = 0;   /* launches up to this size take the LDS-resident kernel: lds_lanes x number of CUs */
   bool mixed = false;      /* two phases per solve: fp32 up to MpcParams.mixed_switch_mu, then fp64 to tol (f32_finish on an F32 handle,
                             * f64_f32_start on an F64 handle) */
@@ -1140,8 +1143,9 @@ struct MpcHandle {
 /* the cut schedule of the multi-phase solve: MpcParams.pass_cut, pass_cut_next[0..2] (a zero ends the list), overridden
  * by MPC_PASS_CUT=a[,b[,c[,d]]] in the environment */
 static void set_wave_limit(MpcHandle *h, const MpcParams *p) {
-  h->wave_max_batch = p->wave_max_batch == 0 ? 64 : (p->wave_max_batch < 0 ? 0 : p->wave_max_batch);
+  h->wave_max_batch = p->wave_max_batch == 0 ? 1024 : (p->wave_max_batch < 0 ? 0 : p->wave_max_batch);
   if (const char *e = getenv("MPC_WAVE_MAX_BATCH")) h->wave_max_batch = atoll(e);      /* (A/B measurements) */
+  if (const char *e = getenv("MPC_WAVE_WHOLE_MAX")) h->wave_whole_max = atoll(e);
   if (p->f64_f32_start == MPC_F32_START_ON || (p->precision == MPC_PRECISION_F32 && p->f32_finish != 0)) h->wave_max_batch = 0;
 }
 
@@ -2018,9 +2022,23 @@ static int launch_solve(MpcHandle *h, int64_t B, int64_t ld, int64_t ldo, const 
   if (h->wave_max_batch > 0 && B <= h->wave_max_batch) {
     --h->counter_seq;                              /* (this path uses no counters: the block stays clean for the next call) */
     MPC_HIP_CHECK(hipEventRecord(h->ev0, s));
-    const size_t lds = (size_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4, h->params.initial_state_rows != 0) * sizeof(R);
-    hipLaunchKernelGGL((mpc_solve_wave_kernel<R>), dim3((unsigned)B), dim3(kBlock), lds, s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
-                       weights, out, traj, status, iters ? iters : h->d_iters);
+    /* lanes per instance: a lane per stage -- 16 up to N = 17 (four instances per wavefront), 32 up to N = 33, else the whole wave;
+     * a launch of a few instances takes the whole wave anyway (its cross-lane reads are v_readlane instead of ds_bpermute) */
+    const int64_t per = (int64_t)mpc::workspace_fields_per_instance(h->params.N, sizeof(R) == 4, h->params.initial_state_rows != 0) * (int64_t)sizeof(R);
+    int lpi = h->params.N - 1 <= 16 ? 16 : (h->params.N - 1 <= 32 ? 32 : 64);
+    if (B <= h->wave_whole_max) lpi = 64;
+    if (const char *e = getenv("MPC_WAVE_LPI")) lpi = atoi(e) == 16 ? 16 : (atoi(e) == 32 ? 32 : 64);
+    if (lpi < h->params.N - 1) lpi = 64;
+    int32_t *it_w = iters ? iters : h->d_iters;
+    if (lpi == 16)
+      hipLaunchKernelGGL((mpc_solve_wave_kernel<R, 16>), dim3((unsigned)((B + 3) / 4)), dim3(kBlock), (size_t)(4 * per), s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
+                         weights, out, traj, status, it_w);
+    else if (lpi == 32)
+      hipLaunchKernelGGL((mpc_solve_wave_kernel<R, 32>), dim3((unsigned)((B + 1) / 2)), dim3(kBlock), (size_t)(2 * per), s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
+                         weights, out, traj, status, it_w);
+    else
+      hipLaunchKernelGGL((mpc_solve_wave_kernel<R, 64>), dim3((unsigned)B), dim3(kBlock), (size_t)per, s, h->params, B, ld, ldo, state, coeffs, yaw_lo, yaw_hi,
+                         weights, out, traj, status, it_w);
     MPC_HIP_CHECK(hipGetLastError());
     MPC_HIP_CHECK(hipEventRecord(h->ev1, s));
     h->timed = true;

@@ -125,8 +125,8 @@ def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torc
 
 @pytest.mark.parametrize("case", ["headline", "N25", "weights", "rows", "f32pure", "N3"])
 def test_one_instance_per_wavefront_is_bitwise_the_lane_kernel(pkg, golden_dir, waypoints, torch_dev, case, monkeypatch):
-    """mpc_solve_wave_kernel (launches of at most 64 instances; MPC_WAVE_MAX_BATCH moves the limit): one instance per wavefront, its
-    N-step variables in LDS, the forward and costate/trial sweeps shared between the lanes -- stage k's model, gains and slacks by
+    """mpc_solve_wave_kernel (launches of at most 1 024 instances; MpcParams.wave_max_batch moves the limit): one instance per
+    wavefront -- or per 16 / 32 neighbouring lanes of one, by the horizon -- its N-step variables in LDS, the forward and costate/trial sweeps shared between the lanes -- stage k's model, gains and slacks by
     lane k, the recursions through the lanes in order with the sequential sweeps' own statements.  Status, iteration count, outputs
     and trajectories are BITWISE those of the lane-per-instance kernel, on SURVEY's population (hard instances included)."""
     import torch
@@ -167,11 +167,22 @@ def test_one_instance_per_wavefront_is_bitwise_the_lane_kernel(pkg, golden_dir, 
         r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
         torch.cuda.synchronize()
         assert np.array_equal(r["out"].cpu().numpy(), a["out"], equal_nan=True)
-    # and the default: a launch of up to 64 instances takes the wave kernel by itself (same bits again)
-    with pkg.BatchedMPC(params, 64, device=0) as mpc:
-        r = mpc.solve_torch(*[x[..., :64].contiguous() for x in ins], weights=t(w[:, :64]) if w is not None else None, want_traj=True)
+    # and the default: a launch of up to 1 024 instances takes the wave kernel by itself (same bits again) -- with a lane group per
+    # instance (16 lanes up to N = 17, 32 up to N = 33), and the whole wave for a launch of a few instances
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
         torch.cuda.synchronize()
-    assert np.array_equal(r["out"].cpu().numpy(), a["out"][:, :64], equal_nan=True) and np.array_equal(r["iters"].cpu().numpy(), a["iters"][:64])
+        assert np.array_equal(r["out"].cpu().numpy(), a["out"], equal_nan=True) and np.array_equal(r["iters"].cpu().numpy(), a["iters"])
+    with pkg.BatchedMPC(params, 8, device=0) as mpc:
+        r = mpc.solve_torch(*[x[..., :8].contiguous() for x in ins], weights=t(w[:, :8]) if w is not None else None, want_traj=True)
+        torch.cuda.synchronize()
+    assert np.array_equal(r["out"].cpu().numpy(), a["out"][:, :8], equal_nan=True) and np.array_equal(r["iters"].cpu().numpy(), a["iters"][:8])
+    # (the env var of the first part forced the whole wave?  no: lanes per instance follow the horizon there too; the whole wave once more)
+    monkeypatch.setenv("MPC_WAVE_LPI", "64")
+    with pkg.BatchedMPC(params, B, device=0) as mpc:
+        r = mpc.solve_torch(*ins, weights=t(w) if w is not None else None, want_traj=True)
+        torch.cuda.synchronize()
+    assert np.array_equal(r["out"].cpu().numpy(), a["out"], equal_nan=True) and np.array_equal(r["status"].cpu().numpy(), a["status"])
 
 
 def test_initial_state_rows_on_the_device(pkg, host_twin, golden_dir, waypoints, torch_dev):

@@ -18,7 +18,7 @@ for config, over, B in (("config-fast.json", {}, 256), ("config-stable.json", di
     ins = (t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]))
     res = {}
     for mode in ("lane", "wave"):
-        if mode == "wave": os.environ["MPC_WAVE_MAX_BATCH"] = "1024"
+        if mode == "wave": os.environ["MPC_WAVE_MAX_BATCH"] = "1024"; os.environ["MPC_WAVE_WHOLE_MAX"] = "0"      # (lanes per instance by the horizon: 16 / 32)
         else: os.environ["MPC_WAVE_MAX_BATCH"] = "0"
         with pkg.BatchedMPC(p, B, device=0) as mpc:
             r = mpc.solve_torch(*ins, want_traj=True); torch.cuda.synchronize()

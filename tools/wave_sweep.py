@@ -17,10 +17,10 @@ full = (t(b["state"]), t(b["coeffs"]), t(b["yaw_lo"]), t(b["yaw_hi"]))
 for B in (1, 8, 64, 256, 1024, 2048, 4096, 8192):
     ins = tuple(x[..., :B].contiguous() for x in full)
     row = {"B": B}
-    for mode in ("lane_fp64", "lane_auto", "wave"):
-        q = p.copy(); q.f64_f32_start = 2 if mode == "lane_auto" else 0
-        if mode == "wave": os.environ["MPC_WAVE_MAX_BATCH"] = "1000000"
-        else: os.environ["MPC_WAVE_MAX_BATCH"] = "0"
+    for mode in ("lane_fp64", "wave64", "wave16"):
+        q = p.copy(); q.f64_f32_start = 0
+        os.environ["MPC_WAVE_MAX_BATCH"] = "0" if mode == "lane_fp64" else "1000000"
+        os.environ["MPC_WAVE_LPI"] = "16" if mode == "wave16" else "64"
         with pkg.BatchedMPC(q, B, device=0) as mpc:
             for _ in range(5): mpc.solve_torch(*ins, want_traj=True); torch.cuda.synchronize()
             ts = []
