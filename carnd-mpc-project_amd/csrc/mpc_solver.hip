@@ -811,8 +811,9 @@ __global__ __launch_bounds__(kBlock, 1) void mpc_solve_lds_kernel(
   if (iters) iters[i] = S.iters;
 }
 
-/* ONE INSTANCE PER WAVEFRONT (launches of a few instances: one MPC::solve() per telemetry message is the reference's own use).
- * The instance's N-step variables live in the workgroup's LDS ([stage][field], 3.7 KB at N = 10 in fp64); every lane of the wave
+/* ONE INSTANCE PER WAVEFRONT, or per LPI = 16 / 32 neighbouring lanes of one (small launches: one MPC::solve() per telemetry
+ * message is the reference's own use).  The instance's N-step variables live in the workgroup's LDS ([stage][field][instance],
+ * 3.7 KB per instance at N = 10 in fp64); every lane of the group
  * runs the solver's state machine on them -- the decisions are wave-uniform -- and the sweeps share their work between the
  * lanes (mpc::Solver<WS, R, true>: backward_wave, forward_wave and the wave form of costate_trial in mpc_core.h). */
 template <class R, int LPI>
@@ -1290,12 +1291,9 @@ extern "C" int mpc_create(const MpcParams *p, int device, int64_t max_batch, Mpc
     if (fn) MPC_CREATE_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
     if (const char *e = getenv("MPC_LDS_MAX_BATCH")) h->lds_max_batch = atoll(e);
   }
-  /* Launches of at most one wavefront's worth of instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the lane
-   * kernel would put them all into one wave, which is bound by the instructions it issues -- one MPC::solve() 0.68 ms; with the
-   * sweeps shared between the lanes 0.30 ms, bitwise the same results.  (A launch of 1 024 instances: 0.54 against 1.22 ms;
-   * from ~4 000 on the lane kernel is ahead, and for many small launches in flight it always is: MpcParams.wave_max_batch moves
-   * the limit or switches the kernel off.)  Not for an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle: those ask for
-   * the two-launch solve. */
+  /* Small launches run ONE INSTANCE PER WAVEFRONT, or per 16 / 32 of its lanes (mpc_solve_wave_kernel): the lane kernel puts 64
+   * instances into a wave, which is bound by the instructions it issues -- one MPC::solve() 0.68 ms; with the sweeps shared
+   * between the lanes 0.30 ms, bitwise the same results (MpcParams.wave_max_batch: default 1 024 instances). */
   set_wave_limit(h, p);
   h->io_stride = (max_batch + 63) / 64 * 64;
   const size_t ws_bytes = (size_t)h->ws_stride * (size_t)(h->io_stride / 64) * (f32 ? sizeof(float) : sizeof(double));

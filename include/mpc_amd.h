@@ -152,8 +152,8 @@ typedef struct MpcParams {
    * so is one the fp64 phase cannot finish from the fp32 iterate: on hard instances fp32 iterates lead into other
    * local minima than fp64 ones.  With that rule the CPU build gives the single-phase solve's status and point (1e-7)
    * on every instance of SURVEY's unfiltered populations (65 536 at N = 10, 32 768 at N = 25).
-   * Default MPC_F32_START_AUTO: long horizons start on the fp32 record.  (Launches of at most 64 instances do not go through
-   * the two-launch solve at all: they run one instance per wavefront, every iteration in fp64 -- DESIGN.md section 6d.)  Measured in round 4 with the tail slices on the
+   * Default MPC_F32_START_AUTO: long horizons start on the fp32 record.  (Launches of at most wave_max_batch instances do not go
+   * through the two-launch solve at all: they run one instance per wavefront, every iteration in fp64 -- DESIGN.md section 6d.)  Measured in round 4 with the tail slices on the
    * tail stream's high priority (windows of 600 batches): N = 25, SURVEY's population 9.8-10.0 M against 7.1-8.8 M solves/s,
    * the filtered generator 11.0-11.9 against 7.6 M; 0 status differences and at most 4.1e-8 rad on the first steering
    * angle over the 32 768 instances of SURVEY's N = 25 population (profiles/r04_f32start_vs_plain.jsonl).  Not for short
@@ -202,12 +202,12 @@ typedef struct MpcParams {
    * step's rounding) at ~4 % of the rate (ten more fields per instance and sweep).  0 (default): not carried; the barrier
    * parameter then comes down one iteration early on a few per cent of the instances.  Same solution either way. */
   int32_t initial_state_rows;
-  /* Launches of at most this many instances run ONE INSTANCE PER WAVEFRONT (mpc_solve_wave_kernel): the
-   * instance's N-step variables in LDS, its stages shared between the lanes of the wave, bitwise the results of the
-   * lane-per-instance kernel.  A latency mapping: one MPC::solve() 0.30 instead of 0.68 ms, a launch of 1 024 instances 0.54
-   * instead of 1.22 ms, level at ~4 000; it spends a SIMD per instance, so many small launches in flight are better off with the
-   * lane kernel.  0 (default) = 64 (what the lane kernel would put into a single wave); < 0 = never.  Not used by an explicit
-   * f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle (those ask for the two-launch solve). */
+  /* Launches of at most this many instances run ONE INSTANCE PER WAVEFRONT -- or per 16 / 32 neighbouring lanes of one, a lane
+   * per stage (mpc_solve_wave_kernel): the instance's N-step variables in LDS, its stages shared between
+   * the lanes, bitwise the results of the lane-per-instance kernel.  A latency mapping: one MPC::solve() 0.30 instead of 0.68 ms,
+   * a launch of 1 024 instances 0.55 instead of 1.21 ms, of 4 096 (N <= 17) 0.74 instead of 1.51 ms, level at ~10 000; it spends
+   * a SIMD per 1-4 instances, so many launches in flight are better off with the lane kernel.  0 (default) = 1 024; < 0 = never.
+   * Not used by an explicit f64_f32_start = 1 or a mixed MPC_PRECISION_F32 handle (those ask for the two-launch solve). */
   int32_t wave_max_batch;
 } MpcParams;
 
