@@ -807,12 +807,7 @@ struct Solver {
     }
     const R rsc = lsm ? R(0.0) : -R(1.0);             /* constraint right-hand side: -c, or 0 for the LS system */
     const R hxy = (lsm ? R(1.0) : R(0.0)) + dw;       /* x and y carry no cost: only the LS identity / regularisation */
-    /* Staging: record j of the iterate (the fields of stage j) sits in buffer (M-1-j)&1.  Stage k needs
-     * (u_k, lam_{k+1}, duals of u_k) from record k -- moved to registers one iteration earlier -- and
-     * (s_k, delta_{k-1}, duals of s_k) from record k-1; record k-2 is requested meanwhile. */
-    ws.stage_drain();
-    ws.stage_fetch_it(0, M - 1, I);
-    ws.template stage_wait<0>();
+    /* the value function behind the last stage (wave-uniform: backward()'s own start) */
     R sn[6];                                    /* s_{k+1} */
     MPC_UNROLL
     for (int i = 0; i < 6; i++) sn[i] = ws.sit(0, M - 1, I, F_S + i);
@@ -1630,8 +1625,7 @@ struct Solver {
               const R mub = lsm ? R(0.0) : mu;
               const R Hpp = lsm ? R(1.0) : c_zlp * islp + c_zup * isup;
               const R Hvv = lsm ? R(1.0) : df * R(2.0) * (wv + wneg0) + c_zlv * islv + c_zuv * isuv;
-              const R Hee = lsm ? R(1.0) : df * R(2.0) * we0, Hcc = lsm ? R(1.0) : df * R(2.0) * wc0;
-              const R gp = mub * (isup - islp);
+                const R gp = mub * (isup - islp);
               const R gv = df * R(2.0) * (wv * (v0k - vref0) + wneg0 * v0k) + mub * (isuv - islv);
               const R ge = df * R(2.0) * we0 * s_o[5], gc = df * R(2.0) * wc0 * s_o[4];
               const R v = s_o[3];
@@ -1640,7 +1634,7 @@ struct Solver {
               const R sp = L.sp, cp = L.cp, se = L.se, ce = L.ce, fp = L.fp, g1 = L.g1;
               const R vdt = v * dt, Apv = del_o * dtLf;
               const R Hpsi2 = (lx * cp + ly * sp) * vdt, Hpv = (lx * sp - ly * cp) * dt;
-              const R Hee2 = lc * vdt * se, Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;
+              const R Hev = -lc * dt * ce, Hvd = -(lp + le) * dtLf;      /* (ds_0 has no x, y, cte, epsi part: their curvature terms drop out) */
               const R L25 = L2 + L5;
               const R n0 = L0 + fp * L4 - g1 * L5;
               const R n1 = L1 - L4;
@@ -1649,8 +1643,7 @@ struct Solver {
                            (Hvv + dw) * ds3 - Hvd * ddk;
               const R n4 = -gc;
               const R n5 = vdt * ce * L4 - ge - Hev * ds3;
-              (void)Hee; (void)Hcc; (void)Hee2;
-              dl0 = n0 - c_l0; dl1 = n1 - c_l1; dl2 = n2 - c_l2; dl3 = n3 - c_l3; dl4 = n4 - c_l4; dl5 = n5 - c_l5;
+                dl0 = n0 - c_l0; dl1 = n1 - c_l1; dl2 = n2 - c_l2; dl3 = n3 - c_l3; dl4 = n4 - c_l4; dl5 = n5 - c_l5;
               lmax = mpc_max(lmax, mpc_max(mpc_max(mpc_max(mpc_abs(dl0), mpc_abs(dl1)), mpc_max(mpc_abs(dl2), mpc_abs(dl3))), mpc_max(mpc_abs(dl4), mpc_abs(dl5))));
             }
             lam_t[0] = c_l0 + alpha_l * dl0; lam_t[1] = c_l1 + alpha_l * dl1; lam_t[2] = c_l2 + alpha_l * dl2;
