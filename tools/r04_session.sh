@@ -252,6 +252,15 @@ u)   # long windows on the final build: the pipeline over several seconds
   timeout -k 10 300 python bench.py --leg configs_4_share --leg-steps 1000 > $OUT/r04u_c4.json 2> $OUT/r04u_c4.err; echo "configs_4_share exit=$?" | tee -a $P
   python -c "import json; l = json.load(open('$OUT/r04u_c4.json')); print('   configs_4_share %.2f M (strict %.2f) %s in flight %d' % (l['solves_per_s'] / 1e6, l['strict_solves_per_s'] / 1e6, l['status_counts'], l['batches_in_flight']))" | tee -a $P
   ;;
+o)   # small launches in flight: the one-instance-per-wavefront kernel (default up to 1 024) against the lane kernel
+  export GPU_MAX_HW_QUEUES=8
+  for b in 256 1024; do
+    run n10_b${b}_wave --steps 600 --batch $b --tail-cut 0 --population filtered
+    MPC_WAVE_MAX_BATCH=0 run n10_b${b}_lane --steps 600 --batch $b --tail-cut 0 --population filtered
+  done
+  MPC_WAVE_MAX_BATCH=4096 run n10_b4096_wave --steps 400 --batch 4096 --tail-cut 0 --population filtered
+  run n10_b4096_lane --steps 400 --batch 4096 --tail-cut 0 --population filtered
+  ;;
 r)   # rates only
   export GPU_MAX_HW_QUEUES=8
   run filtered_c0 --steps 200 --population filtered --tail-cut 0
