@@ -123,15 +123,17 @@ def test_ipopt_stopping_rule_without_the_polish(pkg, golden_dir, waypoints, torc
     assert 0.2 < rp["iters"].mean() - r["iters"].mean() < 1.0
 
 
-@pytest.mark.parametrize("case", ["headline", "N25", "weights", "rows", "f32pure", "N3"])
+@pytest.mark.parametrize("case", ["headline", "N25", "weights", "rows", "f32pure", "N3", "N17", "N18", "N34", "N64"])
 def test_one_instance_per_wavefront_is_bitwise_the_lane_kernel(pkg, golden_dir, waypoints, torch_dev, case, monkeypatch):
     """mpc_solve_wave_kernel (launches of at most 1 024 instances; MpcParams.wave_max_batch moves the limit): one instance per
     wavefront -- or per 16 / 32 neighbouring lanes of one, by the horizon -- its N-step variables in LDS, the forward and costate/trial sweeps shared between the lanes -- stage k's model, gains and slacks by
     lane k, the recursions through the lanes in order with the sequential sweeps' own statements.  Status, iteration count, outputs
     and trajectories are BITWISE those of the lane-per-instance kernel, on SURVEY's population (hard instances included)."""
     import torch
-    over = dict(N=25, dt=0.05) if case == "N25" else (dict(N=3, dt=0.2) if case == "N3" else {})
-    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json" if case == "N25" else "config-fast.json"), **over)
+    # (N17 / N18 and N34: either side of the horizons at which an instance goes from 16 to 32 lanes and from 32 to the whole wave)
+    horizons = {"N25": (25, 0.05), "N3": (3, 0.2), "N17": (17, 0.07), "N18": (18, 0.07), "N34": (34, 0.04), "N64": (64, 0.02)}
+    over = dict(N=horizons[case][0], dt=horizons[case][1]) if case in horizons else {}
+    params = pkg.params_from_json(os.path.join(golden_dir, "config-stable.json" if case in horizons and case != "N3" else "config-fast.json"), **over)
     params.f64_f32_start = 0
     if case == "rows":
         params.initial_state_rows = 1
